@@ -1,0 +1,219 @@
+/*
+ * orbx — C ABI of the MI355X (gfx950) ORB front-end: extraction, descriptor matching and
+ * two-view F/H RANSAC.  Every entry point replaces one interface of the reference
+ * (saifullah3396/orb_slam); the citation after each declaration names it.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; nothing is thrown across this boundary; every call returns an orbx_status.
+ *  - outputs are caller-allocated with an explicit capacity; overflow is reported (ORBX_CAPACITY), never truncated.
+ *  - handles own device buffers and one HIP stream; calls on one handle must not overlap, different handles may.
+ *  - pointers are HOST pointers unless the parameter name starts with d_ (device pointer on the handle's GPU).
+ *  - orbx_keypoint / orbx_match are layout-identical to cv::KeyPoint / cv::DMatch, so std::vector storage
+ *    of the reference's callers can be passed without copies.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ORBX_OK = 0,
+    ORBX_BAD_ARG = 1,
+    ORBX_CAPACITY = 2,
+    ORBX_DEVICE = 3,
+    ORBX_UNSUPPORTED = 4
+} orbx_status;
+
+typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } orbx_keypoint; /* == cv::KeyPoint */
+typedef struct { int32_t query, train, img; float distance; } orbx_match;                      /* == cv::DMatch */
+
+/* Parameters of ORBExtractor (include/orb_slam/geometry/orb_extractor.h:28-37, cfg/orb_extractor.yaml). */
+typedef struct {
+    int32_t n_key_points;    /* default 8000 */
+    float   scale_factor;    /* default 1.2f */
+    int32_t level_pyramid;   /* default 4   */
+    int32_t edge_threshold;  /* 31 */
+    int32_t first_level;     /* 0  (only 0 is supported) */
+    int32_t wta_k;           /* 2  (only 2 is supported) */
+    int32_t patch_size;      /* 31 (only 31 is supported) */
+    int32_t score_threshold; /* FAST threshold, default 20 */
+} orbx_extractor_params;
+
+typedef struct orbx_extractor orbx_extractor;
+typedef struct orbx_matcher orbx_matcher;
+typedef struct orbx_ransac orbx_ransac;
+
+const char* orbx_status_string(orbx_status s);
+/* Last HIP error text seen by the calling thread (empty string when none). */
+const char* orbx_last_error(void);
+/* Number of visible GPUs; 0 when the HIP runtime finds none. */
+int orbx_device_count(void);
+
+/* ------------------------------------------------------------------ extraction ------------------------------ */
+
+/* Replaces ORBExtractor::ORBExtractor (orb_extractor.h:28-81): validates the parameters, builds the pyramid
+   geometry and allocates device buffers for images up to max_width x max_height and batches up to max_batch
+   frames on GPU `device`. */
+orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_width, int max_height,
+                                  int max_batch, int device, orbx_extractor** out);
+void orbx_extractor_destroy(orbx_extractor* h);
+
+/* Replaces the getters scaleFactors()/scaleSigmas()/invScaleSigmas()/logScaleFactor() (orb_extractor.h:39-54,
+   86-92): the reference's own float tables (repeated multiplication), `level_pyramid` entries each. */
+orbx_status orbx_extractor_scale_tables(const orbx_extractor* h, float* scale_factors, float* inv_scale_factors,
+                                        float* scale_sigma_sqrd, float* inv_scale_sigma_sqrd,
+                                        float* log_scale_factor);
+
+/* Replaces ORBExtractor::detect (orb_extractor.h:100-104 -> cv::ORB::detect).  image: 8-bit, channels 1 (gray)
+   or 3 (BGR), `stride` bytes per row.  Writes at most `capacity` keypoints; *count receives the number found
+   (ORBX_CAPACITY when it exceeds capacity, nothing is written then). */
+orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
+                        orbx_keypoint* keypoints, int capacity, int* count);
+
+/* Replaces ORBExtractor::compute (orb_extractor.h:113-119 -> cv::ORB::compute).  keypoints is filtered and,
+   when not sorted by octave, regrouped in place exactly as cv::ORB does; *count is updated; descriptors
+   receives *count rows of 32 bytes. */
+orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
+                         orbx_keypoint* keypoints, int* count, uint8_t* descriptors);
+
+/* Batched detect + compute on frames already resident in HBM (the call sequence of MonoFrame::extractFeatures,
+   src/mono_frame.cpp:72-110, with the host steps between detect and compute left out).
+   d_images: n_frames images, `frame_stride` bytes apart.  Results stay on the device inside the handle
+   (see orbx_extractor_device_results) and are copied to the host arrays when those are non-NULL:
+   keypoints[n_frames * capacity], counts[n_frames], descriptors[n_frames * capacity * 32]. */
+orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n_frames, size_t frame_stride,
+                               int width, int height, int stride, int channels,
+                               orbx_keypoint* keypoints, int capacity, int32_t* counts, uint8_t* descriptors);
+
+/* Device views of the last orbx_extract_batch: keypoints (orbx_keypoint[frames][kp_capacity]),
+   descriptors (uint8[frames][kp_capacity][32]), counts (int32[frames]). */
+orbx_status orbx_extractor_device_results(orbx_extractor* h, const orbx_keypoint** d_keypoints,
+                                          const uint8_t** d_descriptors, const int32_t** d_counts,
+                                          int* kp_capacity);
+
+/* Stage probes used by the parity tests (no counterpart in the reference: they expose the intermediate images
+   cv::ORB keeps private).  what: 0 = pyramid atlas, 1 = FAST score map, 2 = blurred atlas.  The atlas has
+   the geometry reported by orbx_extractor_layout. */
+orbx_status orbx_extractor_layout(const orbx_extractor* h, int width, int height, int* atlas_w, int* atlas_h,
+                                  int32_t* rects_xywh, float* layer_scales);
+orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, uint8_t* out, size_t out_bytes);
+/* Per-kernel launch durations (ms) of the last call, measured with HIP events on the handle's stream.
+   names: gray, resize, fast, nms, emit, harris, blur, brief.  Returns the number written (<= cap). */
+int orbx_extractor_last_timings(const orbx_extractor* h, float* ms, int cap);
+
+/* ------------------------------------------------------------------ matching -------------------------------- */
+
+orbx_status orbx_matcher_create(int device, orbx_matcher** out);
+void orbx_matcher_destroy(orbx_matcher* h);
+
+/* Replaces CVORBMatcher::match (src/geometry/orb_matcher.cpp:671-677 -> cv::BFMatcher(NORM_HAMMING)::match):
+   for every query row the train row of minimum Hamming distance, lowest train index on ties.
+   train_idx[i] = -1 when n_train == 0. */
+orbx_status orbx_match_hamming(orbx_matcher* h, const uint8_t* query, int n_query, const uint8_t* train,
+                               int n_train, int32_t* train_idx, int32_t* distance);
+
+/* Batched form on device-resident descriptors: pair p matches d_query + p*query_stride (n_query[p] rows) against
+   d_train + p*train_stride (n_train[p] rows); results d_train_idx/d_distance[p*out_stride + i] (device). */
+orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, const int32_t* d_n_query,
+                                     size_t query_stride, const uint8_t* d_train, const int32_t* d_n_train,
+                                     size_t train_stride, int n_pairs, int max_query, int max_train,
+                                     int32_t* d_train_idx, int32_t* d_distance, size_t out_stride);
+
+/* Replaces ORBMatcher::filterMatches (orb_matcher.cpp:890-924).  Host arithmetic (sort + unique with the same
+   std:: calls).  In place; *count updated.  n_descriptor_rows = descriptors.rows of the reference call. */
+orbx_status orbx_filter_matches(orbx_match* matches, int* count, int n_descriptor_rows);
+
+/* Replaces BruteForceWithRadiusMatcher::match (orb_matcher.cpp:25-74): per keypoint the reference keypoint
+   within `max_pixel_dist` pixels with the smallest mean absolute descriptor-byte difference. */
+orbx_status orbx_match_radius(orbx_matcher* h, const orbx_keypoint* keypoints, int n, const orbx_keypoint* ref_keypoints,
+                              int n_ref, const uint8_t* descriptors, const uint8_t* ref_descriptors,
+                              double max_pixel_dist, orbx_match* matches, int* count);
+
+/* Frame bucket grid (Frame::setupGrid / assignFeaturesToGrid / pointInGrid, src/frame.cpp:304-367). */
+typedef struct {
+    float min_x, min_y, max_x, max_y; /* Camera::minX() ... (src/geometry/camera.cpp:149-158) */
+    int32_t grid_cols, grid_rows;     /* /orb_slam/tracker/grid_cols, grid_rows */
+    int32_t grid_size_x, grid_size_y; /* undistWidth()/grid_cols, undistHeight()/grid_rows as int (frame.cpp:309-310) */
+} orbx_grid;
+/* Replaces Frame::assignFeaturesToGrid: drops out-of-grid keypoints in place (*count updated) and writes the
+   cells in grid_[col][row] order as CSR: cell_start[cols*rows + 1], cell_items[*count]. */
+orbx_status orbx_assign_grid(const orbx_grid* g, orbx_keypoint* keypoints, int* count, int32_t* cell_start,
+                             int32_t* cell_items);
+
+/* Replaces BruteForceWithProjectionMatcher::match(frame, ref_frame, ref_T_f, ref_map_points, matches)
+   (orb_matcher.cpp:115-255) together with Frame::getFeaturesAroundPoint (frame.cpp:151-218),
+   applyRotationConstraint / createMatches (orb_matcher.h:57-93) and computeThreeMaxima (utils.cpp:202-236).
+   The caller has projected every reference map point into the frame (Frame::worldToCamera / cameraToFrame):
+   proj_xy = pixel, proj_z = depth in the camera frame, ref_has_point[i] = 0 when feature i has no map point,
+   ref_descriptors row i = MapPoint::bestDescriptor().  level_mode: 0 neither, 1 frame in front, 2 frame behind
+   (the z test of orb_matcher.cpp:141-144). */
+orbx_status orbx_match_projection_frame(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,
+                                        const int32_t* cell_items, const orbx_keypoint* keypoints, int n,
+                                        const uint8_t* descriptors, const orbx_keypoint* ref_keypoints, int n_ref,
+                                        const uint8_t* ref_has_point, const float* proj_xy, const float* proj_z,
+                                        const uint8_t* ref_descriptors, const float* scale_factors, int n_levels,
+                                        int level_mode, float radius, int check_orientation,
+                                        orbx_match* matches, int* count);
+
+/* Replaces BruteForceWithProjectionMatcher::match(frame, points_3d, matches) (orb_matcher.cpp:257-352) with the
+   track properties (Frame::isInCameraView, frame.cpp:220-268) supplied by the caller. */
+orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,
+                                         const int32_t* cell_items, const orbx_keypoint* keypoints, int n,
+                                         const uint8_t* descriptors, int n_points, const uint8_t* in_view,
+                                         const float* proj_xy, const int32_t* pred_level, const float* view_cos,
+                                         const uint8_t* point_descriptors, const float* scale_factors, int n_levels,
+                                         float radius, float nn_ratio, orbx_match* matches, int* count);
+
+/* ------------------------------------------------------------------ two-view RANSAC ------------------------- */
+
+orbx_status orbx_ransac_create(int device, orbx_ransac** out);
+void orbx_ransac_destroy(orbx_ransac* h);
+
+/* Replaces Initializer::findFundamentalAndHomography (src/Initializer.cpp:254-304) with everything it calls:
+   geometry::normalizePoints (src/geometry/utils.cpp:18-52), computeFundamentalMat (:61-103),
+   computeHomographyMat (:112-154), findFundamentalMat / checkFundamentalScore (Initializer.cpp:306-444),
+   findHomographyMat / checkHomographyScore (:446-585).
+   points / ref_points: n (x,y) float pairs (points_ / ref_points_).  sets8: iterations x 8 indices into them
+   (ransac_sets_).  Outputs: F, H row-major 3x3; inliers_* n bytes (0/1); scores as the reference stores them;
+   best_iteration[0/1] = winning iteration of F / H, -1 when no hypothesis scored above 0 (the matrix is then
+   left untouched, as fundamental_mat_ / homography_mat_ stay empty in the reference). */
+orbx_status orbx_ransac_fh(orbx_ransac* h, const float* points, const float* ref_points, int n,
+                           const uint32_t* sets8, int iterations, double sigma,
+                           float* F, float* H, uint8_t* inliers_f, uint8_t* inliers_h,
+                           double* score_f, double* score_h, int32_t* best_iteration);
+
+/* Batched form on device-resident data: pair p uses points d_points + p*n*2 etc.; every pair has n points and
+   `iterations` sets.  Outputs are device arrays: d_F/d_H [pairs][9], d_inliers_* [pairs][n], d_scores [pairs][2]
+   (float-rounded scores, F then H), d_best_iteration [pairs][2]. */
+orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const float* d_ref_points, int n,
+                                 const uint32_t* d_sets8, int iterations, int n_pairs, double sigma,
+                                 float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,
+                                 float* d_scores, int32_t* d_best_iteration);
+
+/* Per-hypothesis probe for the parity tests: all hypotheses and scores of one pair (host arrays, iterations
+   rows): F_all/H_all/Hinv_all [it][9], score_f/score_h [it]. */
+orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float* ref_points, int n,
+                               const uint32_t* sets8, int iterations, double sigma,
+                               float* F_all, float* H_all, float* Hinv_all, float* score_f, float* score_h);
+
+/* The reference's set generator (Initializer.cpp:261-277: cumulative std::shuffle, first 8) with a caller-chosen
+   seed per iteration (seed0 + it) in place of std::random_device.  Host arithmetic. */
+orbx_status orbx_ransac_make_sets(int n, int iterations, uint32_t seed0, uint32_t* sets8);
+
+/* Per-kernel launch durations (ms) of the last batch call: normalize, solve, score_f, score_h, select. */
+int orbx_ransac_last_timings(const orbx_ransac* h, float* ms, int cap);
+
+/* Sets the HIP stream (hipStream_t as void*) a handle launches on; NULL restores the handle's own stream. */
+orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream);
+orbx_status orbx_matcher_set_stream(orbx_matcher* h, void* hip_stream);
+orbx_status orbx_ransac_set_stream(orbx_ransac* h, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

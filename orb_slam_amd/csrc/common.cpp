@@ -1,0 +1,36 @@
+// Error reporting shared by the orbx translation units.
+#include "common.h"
+
+namespace orbx {
+static thread_local std::string g_last_error;
+
+void set_last_error(const char* what, hipError_t e, const char* file, int line) {
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+    g_last_error = buf;
+}
+const std::string& last_error() { return g_last_error; }
+}  // namespace orbx
+
+extern "C" {
+
+const char* orbx_status_string(orbx_status s) {
+    switch (s) {
+        case ORBX_OK: return "ok";
+        case ORBX_BAD_ARG: return "bad argument";
+        case ORBX_CAPACITY: return "capacity exceeded";
+        case ORBX_DEVICE: return "device error";
+        case ORBX_UNSUPPORTED: return "unsupported";
+    }
+    return "unknown";
+}
+
+const char* orbx_last_error(void) { return orbx::last_error().c_str(); }
+
+int orbx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,614 @@
+// ORB extractor: host orchestration of the gfx950 kernels behind orbx_detect / orbx_compute /
+// orbx_extract_batch.  Replaces cv::ORB::detect / compute as called by ORBExtractor
+// (reference include/orb_slam/geometry/orb_extractor.h:57-80,100-119).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <thread>
+
+#include "common.h"
+#include "extract_kernels.h"
+#include "host_logic.h"
+
+using namespace orbx;
+
+namespace {
+
+const int kBitPattern31[256 * 4] = {
+#include "bit_pattern_31.inc"
+};
+
+enum Stage { ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_NMS, ST_EMIT, ST_HARRIS, ST_BLUR, ST_BRIEF, ST_COUNT };
+
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+
+}  // namespace
+
+struct orbx_extractor {
+    orbx_extractor_params prm;
+    int device = 0;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // geometry of the current image size
+    int cur_w = -1, cur_h = -1, cur_levels = -1;
+    Geom geom;
+    std::vector<Tile> tiles;
+    std::vector<Coef> coefs;
+    DevBuf<Tile> d_tiles;
+    DevBuf<Coef> d_coefs;
+    DevBuf<BriefPattern> d_pattern;
+    UMax umax;
+    BlurKernel blur_kernel;
+    float harris_scale_sq_sq = 0.f;
+
+    size_t atlas_bytes = 0;
+    int cand_cap = 0;  // candidate corners per frame
+    int kp_cap = 0;    // final keypoints per frame
+
+    DevBuf<uint8_t> d_in, d_atlas, d_score, d_blur, d_desc;
+    DevBuf<unsigned long long> d_mask;
+    DevBuf<Cand> d_cand, d_packed;
+    DevBuf<int> d_level_counts, d_thresholds, d_totals, d_offsets, d_kp_counts;
+    DevBuf<orbx_keypoint> d_kp;
+    PinBuf<Cand> h_packed;
+    PinBuf<int> h_ints;
+    PinBuf<orbx_keypoint> h_kp;
+    PinBuf<uint8_t> h_desc;
+    int last_frames = 0;
+    bool pyramid_valid = false;  // atlas holds the pyramid of the frames of the last detect stage
+
+    StageTimer timer;
+    float last_ms[ST_COUNT] = {};
+};
+
+namespace {
+
+// cv::ORB detectAndCompute(): border, level sizes and atlas placement; computeKeyPoints(): per-level quotas.
+orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
+    if (h->cur_w == w && h->cur_h == hgt && h->cur_levels == nlevels) return ORBX_OK;
+    if (nlevels < 1 || nlevels > kMaxLevels) return ORBX_UNSUPPORTED;
+    const orbx_extractor_params& p = h->prm;
+    Geom& g = h->geom;
+    std::memset(&g, 0, sizeof(g));
+    const int HARRIS_BLOCK_SIZE = 9;
+    int half_patch = p.patch_size / 2;
+    int desc_patch = cv_ceil(half_patch * std::sqrt(2.0));
+    int border = std::max(p.edge_threshold, std::max(desc_patch, HARRIS_BLOCK_SIZE / 2)) + 1;
+    g.border = border;
+    g.nlevels = nlevels;
+    g.edge = p.edge_threshold;
+    auto layer_scale = [&](int level) {
+        return (float)std::pow((double)p.scale_factor, (double)(level - p.first_level));
+    };
+    int level_dy = hgt + border * 2;
+    int ofs_x = 0, ofs_y = 0;
+    int buf_w = (cv_round(w / layer_scale(0)) + border * 2 + 15) & -16;
+    for (int level = 0; level < nlevels; level++) {
+        float scale = layer_scale(level);
+        int sw = cv_round(w / scale), sh = cv_round(hgt / scale);
+        if (sw < 1 || sh < 1) return ORBX_UNSUPPORTED;
+        int whole_w = sw + border * 2, whole_h = sh + border * 2;
+        if (ofs_x + whole_w > buf_w) {
+            ofs_x = 0;
+            ofs_y += level_dy;
+            level_dy = whole_h;
+        }
+        LevelInfo& L = g.L[level];
+        L.x = ofs_x + border;
+        L.y = ofs_y + border;
+        L.w = sw;
+        L.h = sh;
+        L.scale = scale;
+        L.inv_scale = 1.f / scale;
+        ofs_x += whole_w;
+    }
+    g.atlas_w = buf_w;
+    g.atlas_h = ofs_y + level_dy;
+
+    // quotas (computeKeyPoints): levels beyond the configured count (provided keypoints only) get none
+    {
+        int nl = p.level_pyramid;
+        float factor = (float)(1.0 / (double)p.scale_factor);
+        float ndesired = p.n_key_points * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+        int sum = 0;
+        for (int level = 0; level < nlevels; level++) {
+            if (level < nl - 1) {
+                g.L[level].quota = (int)lrintf(ndesired);
+                sum += g.L[level].quota;
+                ndesired *= factor;
+            } else if (level == nl - 1) {
+                g.L[level].quota = std::max(p.n_key_points - sum, 0);
+            } else {
+                g.L[level].quota = 0;
+            }
+        }
+    }
+
+    // mask words, tiles, resize coefficients
+    h->tiles.clear();
+    h->coefs.clear();
+    int words = 0;
+    for (int level = 0; level < nlevels; level++) {
+        LevelInfo& L = g.L[level];
+        L.word_base = words;
+        L.words_per_row = div_up(L.w, 64);
+        words += L.words_per_row * L.h;
+        for (int y0 = 0; y0 < L.h; y0 += kTileH)
+            for (int x0 = 0; x0 < L.w; x0 += kTileW) h->tiles.push_back(Tile{(int16_t)level, 0, (int16_t)x0, (int16_t)y0});
+        if (level > 0) {
+            // cv::resize INTER_LINEAR_EXACT, interpolationLinear<uchar>::getCoeffs: Q8 weights from IEEE double
+            const LevelInfo& S = g.L[level - 1];
+            auto fill = [&](int src, int dst) {
+                double inv_scale = (double)dst / src;
+                double scale = 1.0 / inv_scale;
+                for (int v = 0; v < dst; v++) {
+                    double f = scale * ((double)v + 0.5) - 0.5;
+                    int i = cv_floor(f);
+                    Coef c;
+                    if (i >= 0 && src > 1) {
+                        if (i < src - 1) {
+                            c.ofs = (int16_t)i;
+                            c.w1 = (int16_t)cv_round((f - (double)i) * 256.0);
+                        } else {
+                            c.ofs = (int16_t)(src - 1);
+                            c.w1 = 0;
+                        }
+                    } else {
+                        c.ofs = 0;
+                        c.w1 = 0;
+                    }
+                    h->coefs.push_back(c);
+                }
+            };
+            L.coef_x = (int)h->coefs.size();
+            fill(S.w, L.w);
+            L.coef_y = (int)h->coefs.size();
+            fill(S.h, L.h);
+        }
+    }
+    g.total_words = words;
+    g.total_tiles = (int)h->tiles.size();
+    h->atlas_bytes = (size_t)g.atlas_w * g.atlas_h;
+    ORBX_TRY(h->d_tiles.ensure(h->tiles.size()));
+    ORBX_TRY(h->d_coefs.ensure(std::max<size_t>(h->coefs.size(), 1)));
+    ORBX_HIP(hipMemcpyAsync(h->d_tiles.p, h->tiles.data(), h->tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, h->stream));
+    if (!h->coefs.empty())
+        ORBX_HIP(hipMemcpyAsync(h->d_coefs.p, h->coefs.data(), h->coefs.size() * sizeof(Coef), hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    h->cur_w = w;
+    h->cur_h = hgt;
+    h->cur_levels = nlevels;
+    h->pyramid_valid = false;
+    return ORBX_OK;
+}
+
+orbx_status ensure_buffers(orbx_extractor* h, int frames) {
+    const Geom& g = h->geom;
+    size_t A = h->atlas_bytes;
+    ORBX_TRY(h->d_atlas.ensure(A * frames));
+    ORBX_TRY(h->d_score.ensure(A * frames));
+    ORBX_TRY(h->d_blur.ensure(A * frames));
+    ORBX_TRY(h->d_mask.ensure((size_t)g.total_words * frames));
+    // candidate capacity: a strict 3x3 maximum can occur at most once per 2x2 pixels; a quarter of that bound is
+    // ample for natural images and overflow is reported, not truncated.
+    size_t px = 0;
+    for (int l = 0; l < g.nlevels; l++) px += (size_t)g.L[l].w * g.L[l].h;
+    int cap = (int)std::min<size_t>(std::max<size_t>(px / 16, 4096), 1u << 20);
+    if (cap > h->cand_cap) h->cand_cap = cap;
+    ORBX_TRY(h->d_cand.ensure((size_t)h->cand_cap * frames));
+    ORBX_TRY(h->d_packed.ensure((size_t)h->cand_cap * frames));
+    ORBX_TRY(h->d_level_counts.ensure((size_t)kMaxLevels * frames));
+    ORBX_TRY(h->d_thresholds.ensure((size_t)kMaxLevels * frames));
+    ORBX_TRY(h->d_totals.ensure(frames));
+    ORBX_TRY(h->d_offsets.ensure(frames + 1));
+    ORBX_TRY(h->h_ints.ensure((size_t)frames * (2 * kMaxLevels + 2) + 1));
+    return ORBX_OK;
+}
+
+// Pyramid + FAST + NMS + ordered emission + Harris/angle for `frames` device-resident images.
+orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int frames, size_t frame_stride, int w,
+                             int hgt, int stride, int ch) {
+    const Geom& g = h->geom;
+    hipStream_t s = h->stream;
+    size_t A = h->atlas_bytes;
+    StageTimer& T = h->timer;
+    T.clear();
+    const int border = g.border;
+    T.begin(ST_GRAY, s);
+    {
+        dim3 grid(div_up(w + 2 * border, 256), hgt + 2 * border, frames);
+        hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch,
+                           h->d_atlas.p, A, g.atlas_w, g.L[0].x, g.L[0].y, border);
+    }
+    T.end(ST_GRAY, s);
+    T.begin(ST_RESIZE, s);
+    for (int l = 1; l < g.nlevels; l++) {
+        dim3 grid(div_up(g.L[l].w + 2 * border, 256), g.L[l].h + 2 * border, frames);
+        hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l - 1], g.L[l],
+                           h->d_coefs.p, border);
+    }
+    T.end(ST_RESIZE, s);
+    T.begin(ST_FAST, s);
+    hipLaunchKernelGGL(k_fast_score, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p, A, g,
+                       h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255));
+    T.end(ST_FAST, s);
+    T.begin(ST_NMS, s);
+    hipLaunchKernelGGL(k_nms_mask, dim3(div_up(g.total_words, 4), frames), dim3(256), 0, s, h->d_score.p,
+                       h->d_mask.p, A, g);
+    T.end(ST_NMS, s);
+    T.begin(ST_EMIT, s);
+    hipLaunchKernelGGL(k_emit, dim3(frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, h->d_cand.p,
+                       h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
+    T.end(ST_EMIT, s);
+    T.begin(ST_HARRIS, s);
+    hipLaunchKernelGGL(k_harris_angle, dim3(div_up(h->cand_cap, 4), frames), dim3(256), 0, s, h->d_atlas.p, A, g,
+                       h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq);
+    T.end(ST_HARRIS, s);
+    ORBX_HIP(hipGetLastError());
+    h->pyramid_valid = true;
+    return ORBX_OK;
+}
+
+// Pyramid only (for orbx_compute on its own).
+orbx_status run_pyramid(orbx_extractor* h, const uint8_t* d_images, int frames, size_t frame_stride, int w, int hgt,
+                        int stride, int ch) {
+    const Geom& g = h->geom;
+    hipStream_t s = h->stream;
+    size_t A = h->atlas_bytes;
+    const int border = g.border;
+    h->timer.begin(ST_GRAY, s);
+    dim3 grid(div_up(w + 2 * border, 256), hgt + 2 * border, frames);
+    hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch, h->d_atlas.p,
+                       A, g.atlas_w, g.L[0].x, g.L[0].y, border);
+    h->timer.end(ST_GRAY, s);
+    h->timer.begin(ST_RESIZE, s);
+    for (int l = 1; l < g.nlevels; l++) {
+        dim3 gr(div_up(g.L[l].w + 2 * border, 256), g.L[l].h + 2 * border, frames);
+        hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l - 1], g.L[l],
+                           h->d_coefs.p, border);
+    }
+    h->timer.end(ST_RESIZE, s);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+// Blur + rBRIEF for keypoints already on the device (d_kp / d_kp_counts).
+orbx_status run_describe_stage(orbx_extractor* h, int frames) {
+    const Geom& g = h->geom;
+    hipStream_t s = h->stream;
+    size_t A = h->atlas_bytes;
+    h->timer.begin(ST_BLUR, s);
+    hipLaunchKernelGGL(k_blur, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A, g,
+                       h->d_tiles.p, h->blur_kernel);
+    h->timer.end(ST_BLUR, s);
+    h->timer.begin(ST_BRIEF, s);
+    hipLaunchKernelGGL(k_brief, dim3(div_up(h->kp_cap, 8), frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A, g,
+                       h->d_kp.p, h->d_kp_counts.p, h->kp_cap, h->d_desc.p, h->d_pattern.p);
+    h->timer.end(ST_BRIEF, s);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+void collect_timings(orbx_extractor* h) {
+    for (int i = 0; i < ST_COUNT; i++) h->last_ms[i] = h->timer.ms(i);
+}
+
+// Downloads the candidates of all frames and runs the host part of cv::ORB::detect per frame.
+// out[f] receives the final keypoints of frame f (level-0 coordinates).
+orbx_status select_keypoints(orbx_extractor* h, int frames, std::vector<std::vector<orbx_keypoint>>& out) {
+    const Geom& g = h->geom;
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, h->d_totals.p, frames, h->cand_cap, h->d_offsets.p);
+    hipLaunchKernelGGL(k_pack_cands, dim3(div_up(h->cand_cap, 256), frames), dim3(256), 0, s, h->d_cand.p,
+                       h->cand_cap, h->d_totals.p, h->d_offsets.p, h->d_packed.p);
+    int* hi = h->h_ints.p;
+    int* h_totals = hi;
+    int* h_offsets = hi + frames;
+    int* h_counts = hi + 2 * frames + 1;
+    ORBX_HIP(hipMemcpyAsync(h_totals, h->d_totals.p, sizeof(int) * frames, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h_offsets, h->d_offsets.p, sizeof(int) * (frames + 1), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h_counts, h->d_level_counts.p, sizeof(int) * kMaxLevels * frames, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    for (int f = 0; f < frames; f++)
+        if (h_totals[f] > h->cand_cap) return ORBX_CAPACITY;
+    size_t total = (size_t)h_offsets[frames];
+    ORBX_TRY(h->h_packed.ensure(std::max<size_t>(total, 1)));
+    if (total)
+        ORBX_HIP(hipMemcpyAsync(h->h_packed.p, h->d_packed.p, total * sizeof(Cand), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+
+    out.assign(frames, {});
+    int quotas[kMaxLevels];
+    float scales[kMaxLevels];
+    for (int l = 0; l < g.nlevels; l++) {
+        quotas[l] = g.L[l].quota;
+        scales[l] = g.L[l].scale;
+    }
+    auto work = [&](int f0, int f1) {
+        for (int f = f0; f < f1; f++)
+            host::select_keypoints(h->h_packed.p + h_offsets[f], h_totals[f], h_counts + f * kMaxLevels, g.nlevels,
+                                   quotas, scales, h->prm.patch_size, out[f]);
+    };
+    int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nthreads = std::min(nthreads, frames);
+    if (nthreads <= 1) work(0, frames);
+    else {
+        std::vector<std::thread> th;
+        int per = div_up(frames, nthreads);
+        for (int t = 0; t < nthreads; t++) {
+            int f0 = t * per, f1 = std::min(frames, f0 + per);
+            if (f0 < f1) th.emplace_back(work, f0, f1);
+        }
+        for (auto& t : th) t.join();
+    }
+    return ORBX_OK;
+}
+
+orbx_status check_image_args(const orbx_extractor* h, const void* image, int w, int hgt, int stride, int ch) {
+    if (!h || !image) return ORBX_BAD_ARG;
+    if (ch != 1 && ch != 3) return ORBX_BAD_ARG;
+    if (w <= 0 || hgt <= 0 || stride < w * ch) return ORBX_BAD_ARG;
+    if (w > h->max_w || hgt > h->max_h) return ORBX_CAPACITY;
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_width, int max_height, int max_batch,
+                                  int device, orbx_extractor** out) {
+    if (!params || !out || max_width <= 0 || max_height <= 0 || max_batch <= 0) return ORBX_BAD_ARG;
+    if (params->first_level != 0 || params->wta_k != 2 || params->patch_size != 31) return ORBX_UNSUPPORTED;
+    if (params->level_pyramid < 1 || params->level_pyramid > kMaxLevels) return ORBX_UNSUPPORTED;
+    if (params->n_key_points < 0 || !(params->scale_factor > 1.0f) || params->edge_threshold < 0) return ORBX_BAD_ARG;
+    if (max_width > 16384 || max_height > 16384) return ORBX_UNSUPPORTED;
+    ORBX_HIP(hipSetDevice(device));
+    orbx_extractor* h = new orbx_extractor();
+    h->prm = *params;
+    h->device = device;
+    h->max_w = max_width;
+    h->max_h = max_height;
+    h->max_batch = max_batch;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return ORBX_DEVICE;
+    }
+    h->stream = h->own_stream;
+    orbx_status st = h->timer.init();
+    if (st != ORBX_OK) { orbx_extractor_destroy(h); return st; }
+
+    // cv::ORB computeKeyPoints(): umax table of the circular patch
+    {
+        int half_patch = params->patch_size / 2;
+        int umax[32] = {};
+        int v, v0, vmax = cv_floor(half_patch * std::sqrt(2.f) / 2 + 1);
+        int vmin = cv_ceil(half_patch * std::sqrt(2.f) / 2);
+        for (v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt((double)half_patch * half_patch - v * v));
+        for (v = half_patch, v0 = 0; v >= vmin; --v) {
+            while (umax[v0] == umax[v0 + 1]) ++v0;
+            umax[v] = v0;
+            ++v0;
+        }
+        for (int i = 0; i < 16; i++) h->umax.v[i] = umax[i];
+    }
+    // cv::getGaussianKernel(7, 2, CV_32F) converted to Q8 (createSeparableLinearFilter, 8-bit symmetric smooth)
+    {
+        const int n = 7;
+        const double sigma = 2.0;
+        double scale2x = -0.5 / (sigma * sigma);
+        float cf[7];
+        double sum = 0;
+        for (int i = 0; i < n; i++) {
+            double x = i - (n - 1) * 0.5;
+            cf[i] = (float)std::exp(scale2x * x * x);
+            sum += cf[i];
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < n; i++) {
+            cf[i] = (float)(cf[i] * sum);
+            h->blur_kernel.k[i] = (int)lrintf(cf[i] * 256.f);
+        }
+    }
+    {
+        float scale = 1.f / ((1 << 2) * 7 * 255.f);
+        h->harris_scale_sq_sq = scale * scale * scale * scale;
+    }
+    BriefPattern bp;
+    for (int i = 0; i < 1024; i++) bp.p[i] = (int8_t)kBitPattern31[i];
+    st = h->d_pattern.ensure(1);
+    if (st == ORBX_OK && hipMemcpy(h->d_pattern.p, &bp, sizeof(bp), hipMemcpyHostToDevice) != hipSuccess) st = ORBX_DEVICE;
+    if (st == ORBX_OK) st = h->d_in.ensure((size_t)max_width * max_height * 3);
+    if (st != ORBX_OK) { orbx_extractor_destroy(h); return st; }
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_extractor_destroy(orbx_extractor* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    h->d_tiles.release(); h->d_coefs.release(); h->d_pattern.release();
+    h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
+    h->d_mask.release(); h->d_cand.release(); h->d_packed.release();
+    h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
+    h->d_kp_counts.release(); h->d_kp.release();
+    h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();
+    h->timer.destroy();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream) {
+    if (!h) return ORBX_BAD_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_scale_tables(const orbx_extractor* h, float* sf, float* isf, float* ss, float* iss,
+                                        float* log_sf) {
+    if (!h) return ORBX_BAD_ARG;
+    host::scale_tables(h->prm.scale_factor, h->prm.level_pyramid, sf, isf, ss, iss, log_sf);
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_layout(const orbx_extractor* hc, int width, int height, int* atlas_w, int* atlas_h,
+                                  int32_t* rects, float* scales) {
+    orbx_extractor* h = const_cast<orbx_extractor*>(hc);
+    if (!h || width <= 0 || height <= 0) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
+    if (atlas_w) *atlas_w = h->geom.atlas_w;
+    if (atlas_h) *atlas_h = h->geom.atlas_h;
+    for (int l = 0; l < h->geom.nlevels; l++) {
+        if (rects) {
+            rects[4 * l] = h->geom.L[l].x;
+            rects[4 * l + 1] = h->geom.L[l].y;
+            rects[4 * l + 2] = h->geom.L[l].w;
+            rects[4 * l + 3] = h->geom.L[l].h;
+        }
+        if (scales) scales[l] = h->geom.L[l].scale;
+    }
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, uint8_t* out, size_t out_bytes) {
+    if (!h || !out || frame < 0 || frame >= std::max(h->last_frames, 1)) return ORBX_BAD_ARG;
+    if (out_bytes < h->atlas_bytes) return ORBX_CAPACITY;
+    ORBX_HIP(hipSetDevice(h->device));
+    const uint8_t* src = what == 0 ? h->d_atlas.p : what == 1 ? h->d_score.p : what == 2 ? h->d_blur.p : nullptr;
+    if (!src) return ORBX_BAD_ARG;
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    ORBX_HIP(hipMemcpy(out, src + (size_t)frame * h->atlas_bytes, h->atlas_bytes, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_extractor_last_timings(const orbx_extractor* h, float* ms, int cap) {
+    if (!h || !ms) return 0;
+    int n = std::min(cap, (int)ST_COUNT);
+    for (int i = 0; i < n; i++) ms[i] = h->last_ms[i];
+    return n;
+}
+
+orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
+                        orbx_keypoint* keypoints, int capacity, int* count) {
+    if (!count || capacity < 0 || (capacity > 0 && !keypoints)) return ORBX_BAD_ARG;
+    *count = 0;
+    ORBX_TRY(check_image_args(h, image, width, height, stride, channels));
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
+    ORBX_TRY(ensure_buffers(h, 1));
+    size_t bytes = (size_t)stride * height;
+    ORBX_TRY(h->d_in.ensure(bytes));
+    ORBX_HIP(hipMemcpyAsync(h->d_in.p, image, bytes, hipMemcpyHostToDevice, h->stream));
+    h->last_frames = 1;
+    ORBX_TRY(run_detect_stage(h, h->d_in.p, 1, bytes, width, height, stride, channels));
+    std::vector<std::vector<orbx_keypoint>> sel;
+    ORBX_TRY(select_keypoints(h, 1, sel));
+    collect_timings(h);
+    *count = (int)sel[0].size();
+    if (*count > capacity) return ORBX_CAPACITY;
+    std::copy(sel[0].begin(), sel[0].end(), keypoints);
+    return ORBX_OK;
+}
+
+orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
+                         orbx_keypoint* keypoints, int* count, uint8_t* descriptors) {
+    if (!count || *count < 0 || (*count > 0 && (!keypoints || !descriptors))) return ORBX_BAD_ARG;
+    ORBX_TRY(check_image_args(h, image, width, height, stride, channels));
+    int n = *count;
+    // cv::ORB detectAndCompute(useProvidedKeypoints): number of levels from the keypoints
+    int nlevels = 0;
+    bool sorted = true;
+    for (int i = 0; i < n; i++) {
+        int level = keypoints[i].octave;
+        if (level < 0) return ORBX_BAD_ARG;
+        if (i > 0 && level < keypoints[i - 1].octave) sorted = false;
+        nlevels = std::max(nlevels, level);
+    }
+    nlevels++;
+    if (nlevels > kMaxLevels) return ORBX_UNSUPPORTED;
+    std::vector<orbx_keypoint> k(keypoints, keypoints + n);
+    host::run_by_image_border(k, width, height, h->prm.edge_threshold);
+    if (!sorted) host::regroup_by_level(k, nlevels);
+    if (k.empty()) { *count = 0; return ORBX_OK; }
+
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(build_geometry(h, width, height, std::max(nlevels, h->prm.level_pyramid)));
+    ORBX_TRY(ensure_buffers(h, 1));
+    size_t bytes = (size_t)stride * height;
+    ORBX_TRY(h->d_in.ensure(bytes));
+    ORBX_HIP(hipMemcpyAsync(h->d_in.p, image, bytes, hipMemcpyHostToDevice, h->stream));
+    h->last_frames = 1;
+    h->timer.clear();
+    ORBX_TRY(run_pyramid(h, h->d_in.p, 1, bytes, width, height, stride, channels));
+    int m = (int)k.size();
+    if (m > h->kp_cap) h->kp_cap = m;
+    ORBX_TRY(h->d_kp.ensure((size_t)h->kp_cap));
+    ORBX_TRY(h->d_desc.ensure((size_t)h->kp_cap * 32));
+    ORBX_TRY(h->d_kp_counts.ensure(1));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, k.data(), sizeof(orbx_keypoint) * m, hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp_counts.p, &m, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    ORBX_TRY(run_describe_stage(h, 1));
+    ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)m * 32, hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    collect_timings(h);
+    std::copy(k.begin(), k.end(), keypoints);
+    *count = m;
+    return ORBX_OK;
+}
+
+orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n_frames, size_t frame_stride,
+                               int width, int height, int stride, int channels, orbx_keypoint* keypoints,
+                               int capacity, int32_t* counts, uint8_t* descriptors) {
+    ORBX_TRY(check_image_args(h, d_images, width, height, stride, channels));
+    if (n_frames <= 0 || capacity <= 0 || frame_stride < (size_t)stride * height) return ORBX_BAD_ARG;
+    if (n_frames > h->max_batch) return ORBX_CAPACITY;
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
+    ORBX_TRY(ensure_buffers(h, n_frames));
+    h->last_frames = n_frames;
+    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels));
+    std::vector<std::vector<orbx_keypoint>> sel;
+    ORBX_TRY(select_keypoints(h, n_frames, sel));
+    int max_n = 0;
+    for (auto& v : sel) max_n = std::max(max_n, (int)v.size());
+    if (max_n > capacity) return ORBX_CAPACITY;
+    h->kp_cap = capacity;
+    ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
+    ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
+    ORBX_TRY(h->d_kp_counts.ensure(n_frames));
+    ORBX_TRY(h->h_kp.ensure((size_t)capacity * n_frames));
+    int* h_counts = h->h_ints.p;
+    for (int f = 0; f < n_frames; f++) {
+        h_counts[f] = (int)sel[f].size();
+        std::copy(sel[f].begin(), sel[f].end(), h->h_kp.p + (size_t)f * capacity);
+    }
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
+                            hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp_counts.p, h_counts, sizeof(int) * n_frames, hipMemcpyHostToDevice, h->stream));
+    ORBX_TRY(run_describe_stage(h, n_frames));
+    if (descriptors)
+        ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost,
+                                h->stream));
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    collect_timings(h);
+    if (counts) std::memcpy(counts, h_counts, sizeof(int) * n_frames);
+    if (keypoints) std::memcpy(keypoints, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames);
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_device_results(orbx_extractor* h, const orbx_keypoint** d_keypoints,
+                                          const uint8_t** d_descriptors, const int32_t** d_counts, int* kp_capacity) {
+    if (!h) return ORBX_BAD_ARG;
+    if (d_keypoints) *d_keypoints = h->d_kp.p;
+    if (d_descriptors) *d_descriptors = h->d_desc.p;
+    if (d_counts) *d_counts = h->d_kp_counts.p;
+    if (kp_capacity) *kp_capacity = h->kp_cap;
+    return ORBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,444 @@
+// Device kernels of the ORB extractor (gfx950).  All arithmetic that decides a result is integer, or float
+// evaluated without contraction (the translation unit is compiled with -ffp-contract=off), so results are
+// bit-identical to the scalar CPU evaluation order of cv::ORB.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "extract_types.h"
+#include "orbx.h"
+
+namespace orbx {
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// K1: BGR/gray -> level 0 of the atlas including its reflect-101 border.
+// cv::cvtColor(BGR2GRAY) 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+__global__ void k_gray_level0(const uint8_t* __restrict__ img, size_t frame_stride, int w, int h, int stride, int ch,
+                              uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw, int rx, int ry, int border) {
+    int tx = blockIdx.x * blockDim.x + threadIdx.x;
+    int ty = blockIdx.y;
+    int b = blockIdx.z;
+    if (tx >= w + 2 * border) return;
+    int sx = reflect101(tx - border, w), sy = reflect101(ty - border, h);
+    const uint8_t* s = img + (size_t)b * frame_stride + (size_t)sy * stride + (size_t)sx * ch;
+    int g;
+    if (ch == 1) g = s[0];
+    else g = (s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14;
+    atlas[(size_t)b * atlas_bytes + (size_t)(ry - border + ty) * aw + (rx - border + tx)] = (uint8_t)g;
+}
+
+// K2: level l from level l-1 by cv::resize(INTER_LINEAR_EXACT) (Q8.8 horizontal, Q16.16 vertical, round half up),
+// written together with its reflect-101 border.
+__global__ void k_resize_level(uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw, LevelInfo src, LevelInfo dst,
+                               const Coef* __restrict__ coef, int border) {
+    int tx = blockIdx.x * blockDim.x + threadIdx.x;
+    int ty = blockIdx.y;
+    int b = blockIdx.z;
+    if (tx >= dst.w + 2 * border) return;
+    int x = reflect101(tx - border, dst.w), y = reflect101(ty - border, dst.h);
+    Coef cx = coef[dst.coef_x + x], cy = coef[dst.coef_y + y];
+    uint8_t* base = atlas + (size_t)b * atlas_bytes;
+    int o = cx.ofs, o1 = min(o + 1, src.w - 1);
+    int r = cy.ofs, r1 = min(r + 1, src.h - 1);
+    const uint8_t* p0 = base + (size_t)(src.y + r) * aw + src.x;
+    const uint8_t* p1 = base + (size_t)(src.y + r1) * aw + src.x;
+    uint32_t wx1 = (uint32_t)cx.w1, wx0 = 256u - wx1, wy1 = (uint32_t)cy.w1, wy0 = 256u - wy1;
+    uint32_t h0 = wx0 * p0[o] + wx1 * p0[o1];
+    uint32_t h1 = wx0 * p1[o] + wx1 * p1[o1];
+    uint32_t v = wy0 * h0 + wy1 * h1;
+    base[(size_t)(dst.y - border + ty) * aw + (dst.x - border + tx)] = (uint8_t)((v + (1u << 15)) >> 16);
+}
+
+// 9 contiguous set bits in a circular 16-bit mask.
+__device__ __forceinline__ bool has_arc9(unsigned m) {
+    m |= m << 16;
+    unsigned r = m & (m >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= m >> 8;
+    return r != 0;
+}
+
+// K3: FAST-9/16 corner score of every level pixel (cv::FAST_t<16> + cornerScore<16>); 0 = not a corner.
+// One 64x16 tile per workgroup, staged in LDS with a 3-pixel halo.
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
+                                                    size_t atlas_bytes, Geom g, const Tile* __restrict__ tiles,
+                                                    int threshold) {
+    __shared__ uint8_t t[kTileH + 6][kTileW + 8];
+    const Tile tl = tiles[blockIdx.x];
+    const LevelInfo L = g.L[tl.level];
+    const int b = blockIdx.y;
+    const int aw = g.atlas_w;
+    const uint8_t* base = atlas + (size_t)b * atlas_bytes;
+    const int ax0 = L.x + tl.x0 - 3, ay0 = L.y + tl.y0 - 3;
+    for (int i = threadIdx.x; i < (kTileH + 6) * (kTileW + 6); i += 256) {
+        int r = i / (kTileW + 6), c = i - r * (kTileW + 6);
+        int ax = min(max(ax0 + c, 0), aw - 1), ay = min(max(ay0 + r, 0), g.atlas_h - 1);
+        t[r][c] = base[(size_t)ay * aw + ax];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    const int x = tl.x0 + lx;
+    constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int ly = (threadIdx.x >> 6) + rr * 4;
+        const int y = tl.y0 + ly;
+        if (x >= L.w || y >= L.h) continue;
+        int s = 0;
+        if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
+            const int v = t[ly + 3][lx + 3];
+            const int lo = v - threshold, hi = v + threshold;
+            int p[16];
+            unsigned dark = 0, bright = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                p[k] = t[ly + 3 + dy[k]][lx + 3 + dx[k]];
+                dark |= (unsigned)(p[k] < lo) << k;
+                bright |= (unsigned)(p[k] > hi) << k;
+            }
+            if (has_arc9(dark) || has_arc9(bright)) {
+                // score = max(threshold, best over the 16 arcs of 9 of min(v-p), same for p-v) - 1
+                int d[16], m2[16], m4[16], x2[16], x4[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) d[k] = v - p[k];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    m2[k] = min(d[k], d[(k + 1) & 15]);
+                    x2[k] = max(d[k], d[(k + 1) & 15]);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    m4[k] = min(m2[k], m2[(k + 2) & 15]);
+                    x4[k] = max(x2[k], x2[(k + 2) & 15]);
+                }
+                int best = threshold;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    int mn = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
+                    int mx = max(max(x4[k], x4[(k + 4) & 15]), d[(k + 8) & 15]);
+                    best = max(best, max(mn, -mx));
+                }
+                s = best - 1;
+            }
+        }
+        score[(size_t)b * atlas_bytes + (size_t)(L.y + y) * aw + L.x + x] = (uint8_t)s;
+    }
+}
+
+// K4a: 3x3 strict non-max suppression + cv::KeyPointsFilter::runByImageBorder as one bit per level pixel
+// (one 64-bit ballot word per wavefront, rows padded to whole words).
+__global__ __launch_bounds__(256) void k_nms_mask(const uint8_t* __restrict__ score, unsigned long long* __restrict__ mask,
+                                                  size_t atlas_bytes, Geom g) {
+    const int word = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    if (word >= g.total_words) return;
+    int l = 0;
+    while (l + 1 < g.nlevels && word >= g.L[l + 1].word_base) l++;
+    const LevelInfo L = g.L[l];
+    const int r = word - L.word_base;
+    const int y = r / L.words_per_row;
+    const int x = (r - y * L.words_per_row) * 64 + lane;
+    const int lo = max(3, g.edge);
+    bool kp = false;
+    const bool level_ok = g.edge <= 0 || (L.w > 2 * g.edge && L.h > 2 * g.edge);
+    if (level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo) {
+        const int aw = g.atlas_w;
+        const uint8_t* s = score + (size_t)b * atlas_bytes + (size_t)(L.y + y) * aw + L.x + x;
+        const int c = s[0];
+        if (c)
+            kp = c > s[1] && c > s[-1] && c > s[-aw - 1] && c > s[-aw] && c > s[-aw + 1] && c > s[aw - 1] &&
+                 c > s[aw] && c > s[aw + 1];
+    }
+    const unsigned long long m = __ballot(kp);
+    if (lane == 0) mask[(size_t)b * g.total_words + word] = m;
+}
+
+// K4b: ordered emission. One workgroup per frame walks the mask words in level-major raster order and appends the
+// set bits at their exact rank, so the candidate list has the order cv::FAST emits.  Also builds the per-level
+// histogram of FAST scores and from it the score of the (2*quota)-th best corner: the value
+// KeyPointsFilter::retainBest(2*quota) keeps everything at or above.
+__global__ __launch_bounds__(256) void k_emit(const unsigned long long* __restrict__ mask,
+                                              const uint8_t* __restrict__ score, size_t atlas_bytes, Geom g,
+                                              Cand* __restrict__ cand, int cap, int* __restrict__ level_counts,
+                                              int* __restrict__ thresholds, int* __restrict__ totals) {
+    __shared__ int hist[kMaxLevels][256];
+    __shared__ int lcount[kMaxLevels];
+    __shared__ int wave_sum[4];
+    __shared__ int running;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kMaxLevels * 256; i += 256) (&hist[0][0])[i] = 0;
+    if (tid < kMaxLevels) lcount[tid] = 0;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    const unsigned long long* mk = mask + (size_t)b * g.total_words;
+    const uint8_t* sc = score + (size_t)b * atlas_bytes;
+    Cand* out = cand + (size_t)b * cap;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int base = 0; base < g.total_words; base += 256) {
+        const int word = base + tid;
+        unsigned long long m = word < g.total_words ? mk[word] : 0ull;
+        const int c = __popcll(m);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wave_sum[wv] = incl;
+        __syncthreads();
+        int before = running;
+        for (int k = 0; k < wv; k++) before += wave_sum[k];
+        int pos = before + incl - c;
+        if (m) {
+            int l = 0;
+            while (l + 1 < g.nlevels && word >= g.L[l + 1].word_base) l++;
+            const LevelInfo L = g.L[l];
+            const int r = word - L.word_base;
+            const int y = r / L.words_per_row;
+            const int x0 = (r - y * L.words_per_row) * 64;
+            atomicAdd(&lcount[l], c);
+            while (m) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int x = x0 + bit;
+                const int s = sc[(size_t)(L.y + y) * g.atlas_w + L.x + x];
+                if (pos < cap) {
+                    Cand cd;
+                    cd.x = (uint16_t)x;
+                    cd.y = (uint16_t)y;
+                    cd.score = (uint8_t)s;
+                    cd.level = (uint8_t)l;
+                    cd.pad = 0;
+                    cd.harris = 0.f;
+                    cd.angle = -1.f;
+                    out[pos] = cd;
+                }
+                atomicAdd(&hist[l][s], 1);
+                pos++;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) running += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+    }
+    if (tid < g.nlevels) {
+        const int n = lcount[tid];
+        const int want = 2 * g.L[tid].quota;
+        int t = 0;
+        if (n > want) {
+            if (want == 0) t = 256;
+            else {
+                int acc = 0;
+                for (int s = 255; s >= 0; s--) {
+                    acc += hist[tid][s];
+                    if (acc >= want) { t = s; break; }
+                }
+            }
+        }
+        level_counts[b * kMaxLevels + tid] = n;
+        thresholds[b * kMaxLevels + tid] = t;
+    }
+    if (tid == 0) totals[b] = running;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// cv::fastAtan2 (scalar atan_f32), degrees in [0, 360).
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+struct UMax { int v[16]; };
+
+// K5/K6: Harris response (cv::ORB HarrisResponses, 7x7 block, k = 0.04) and intensity-centroid angle
+// (cv::ORB ICAngles, radius 15) of one candidate per wavefront.  Candidates whose FAST score is below the level's
+// retainBest(2*quota) value are skipped: cv::ORB has dropped them before it computes either quantity.
+__global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
+                                                      Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
+                                                      const int* __restrict__ thresholds, UMax umax,
+                                                      float scale_sq_sq) {
+    const int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    if (idx >= cap || idx >= totals[b]) return;
+    Cand* cp = cand + (size_t)b * cap + idx;
+    const Cand c = *cp;
+    if ((int)c.score < thresholds[b * kMaxLevels + c.level]) return;
+    const LevelInfo L = g.L[c.level];
+    const int aw = g.atlas_w;
+    const uint8_t* center = atlas + (size_t)b * atlas_bytes + (size_t)(L.y + c.y) * aw + L.x + c.x;
+    int ha = 0, hb = 0, hc = 0;
+    if (lane < 49) {
+        const int i = lane / 7 - 3, j = lane - (lane / 7) * 7 - 3;
+        const uint8_t* p = center + i * aw + j;
+        const int Ix = (p[1] - p[-1]) * 2 + (p[-aw + 1] - p[-aw - 1]) + (p[aw + 1] - p[aw - 1]);
+        const int Iy = (p[aw] - p[-aw]) * 2 + (p[aw - 1] - p[-aw - 1]) + (p[aw + 1] - p[-aw + 1]);
+        ha = Ix * Ix;
+        hb = Iy * Iy;
+        hc = Ix * Iy;
+    }
+    ha = wave_sum_i32(ha);
+    hb = wave_sum_i32(hb);
+    hc = wave_sum_i32(hc);
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - 15;
+        const int d = umax.v[v < 0 ? -v : v];
+        const uint8_t* row = center + v * aw;
+        int s = 0, su = 0;
+        for (int u = -d; u <= d; u++) {
+            const int val = row[u];
+            s += val;
+            su += u * val;
+        }
+        m10 = su;
+        m01 = v * s;
+    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
+    if (lane == 0) {
+        const float fa = (float)ha, fb = (float)hb, fc = (float)hc;
+        const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+        cp->harris = resp;
+        cp->angle = fast_atan2_deg((float)m01, (float)m10);
+    }
+}
+
+// Packs the per-frame candidate lists back to back (offsets = exclusive prefix of totals) for one D2H copy.
+__global__ void k_scan_totals(const int* __restrict__ totals, int n, int cap, int* __restrict__ offsets) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < n; i++) {
+            offsets[i] = acc;
+            acc += min(totals[i], cap);
+        }
+        offsets[n] = acc;
+    }
+}
+
+__global__ void k_pack_cands(const Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
+                             const int* __restrict__ offsets, Cand* __restrict__ packed) {
+    const int b = blockIdx.y;
+    const int n = min(totals[b], cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) packed[offsets[b] + i] = cand[(size_t)b * cap + i];
+}
+
+struct BlurKernel { int k[7]; };
+
+// K7: cv::GaussianBlur(7x7, sigma 2) of every level as cv::ORB applies it (8-bit fixed-point separable filter,
+// taps round(g*256), rows then columns, (sum + 2^15) >> 16).  Reads the un-blurred atlas including the level's
+// border, writes level interiors only.
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ blurred,
+                                              size_t atlas_bytes, Geom g, const Tile* __restrict__ tiles,
+                                              BlurKernel bk) {
+    __shared__ uint8_t src[kTileH + 6][kTileW + 8];
+    __shared__ int hrow[kTileH + 6][kTileW];
+    const Tile tl = tiles[blockIdx.x];
+    const LevelInfo L = g.L[tl.level];
+    const int b = blockIdx.y;
+    const int aw = g.atlas_w;
+    const uint8_t* base = atlas + (size_t)b * atlas_bytes;
+    const int ax0 = L.x + tl.x0 - 3, ay0 = L.y + tl.y0 - 3;
+    for (int i = threadIdx.x; i < (kTileH + 6) * (kTileW + 6); i += 256) {
+        int r = i / (kTileW + 6), c = i - r * (kTileW + 6);
+        int ax = min(max(ax0 + c, 0), aw - 1), ay = min(max(ay0 + r, 0), g.atlas_h - 1);
+        src[r][c] = base[(size_t)ay * aw + ax];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (kTileH + 6) * kTileW; i += 256) {
+        int r = i >> 6, c = i & 63;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += bk.k[k] * src[r][c + k];
+        hrow[r][c] = acc;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    const int x = tl.x0 + lx;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int ly = (threadIdx.x >> 6) + rr * 4;
+        const int y = tl.y0 + ly;
+        if (x >= L.w || y >= L.h) continue;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += bk.k[k] * hrow[ly + k][lx];
+        int v = (acc + (1 << 15)) >> 16;
+        blurred[(size_t)b * atlas_bytes + (size_t)(L.y + y) * aw + L.x + x] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+struct BriefPattern { int8_t p[1024]; };
+
+// K8: rotated BRIEF (cv::ORB computeOrbDescriptors, WTA_K = 2).  32 lanes per keypoint, one descriptor byte per
+// lane.  Samples inside the level come from the blurred plane; samples in the level's border come from the
+// un-blurred atlas, which is what cv::ORB reads there (it blurs level interiors in place).
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ blurred,
+                                               size_t atlas_bytes, Geom g, const orbx_keypoint* __restrict__ kps,
+                                               const int* __restrict__ counts, int kp_cap,
+                                               uint8_t* __restrict__ desc, const BriefPattern* __restrict__ pat) {
+    const int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 5);
+    const int lane = threadIdx.x & 31;
+    const int b = blockIdx.y;
+    if (idx >= counts[b] || idx >= kp_cap) return;
+    const orbx_keypoint kp = kps[(size_t)b * kp_cap + idx];
+    const LevelInfo L = g.L[kp.octave];
+    float angle = kp.angle;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    const float a = (float)cos((double)angle), bb = (float)sin((double)angle);
+    const int cx = __float2int_rn(kp.x * L.inv_scale), cy = __float2int_rn(kp.y * L.inv_scale);
+    const int aw = g.atlas_w;
+    const size_t fo = (size_t)b * atlas_bytes;
+    const int8_t* q = pat->p + lane * 32;
+    int val = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++, q += 4) {
+        const float x0 = q[0] * a - q[1] * bb, y0 = q[0] * bb + q[1] * a;
+        const float x1 = q[2] * a - q[3] * bb, y1 = q[2] * bb + q[3] * a;
+        const int sx0 = cx + __float2int_rn(x0), sy0 = cy + __float2int_rn(y0);
+        const int sx1 = cx + __float2int_rn(x1), sy1 = cy + __float2int_rn(y1);
+        const bool in0 = (unsigned)sx0 < (unsigned)L.w && (unsigned)sy0 < (unsigned)L.h;
+        const bool in1 = (unsigned)sx1 < (unsigned)L.w && (unsigned)sy1 < (unsigned)L.h;
+        const size_t o0 = fo + (size_t)(L.y + sy0) * aw + L.x + sx0;
+        const size_t o1 = fo + (size_t)(L.y + sy1) * aw + L.x + sx1;
+        const int t0 = in0 ? blurred[o0] : atlas[o0];
+        const int t1 = in1 ? blurred[o1] : atlas[o1];
+        val |= (int)(t0 < t1) << bit;
+    }
+    desc[((size_t)b * kp_cap + idx) * 32 + lane] = (uint8_t)val;
+}
+
+}  // namespace orbx

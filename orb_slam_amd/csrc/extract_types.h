@@ -1,0 +1,53 @@
+// Plain data shared by the extractor kernels and the host logic (no device code).
+#pragma once
+
+#include <stdint.h>
+
+namespace orbx {
+
+constexpr int kMaxLevels = 16;
+constexpr int kTileW = 64;   // FAST / blur tile: 64 x 16 level pixels per 256-thread workgroup
+constexpr int kTileH = 16;
+
+struct LevelInfo {
+    int x, y, w, h;        // un-padded level rectangle inside the atlas
+    int word_base;         // first 64-pixel mask word of this level
+    int words_per_row;     // ceil(w / 64)
+    int quota;             // keypoints wanted on this level (cv::ORB nfeaturesPerLevel)
+    int coef_x, coef_y;    // offsets of this level's resize coefficient rows in the coefficient table
+    float scale;           // cv::ORB layer scale  (float)pow(scaleFactor, level)
+    float inv_scale;       // 1.f / scale
+};
+
+struct Geom {
+    int nlevels;
+    int atlas_w, atlas_h;
+    int border;
+    int total_words;
+    int total_tiles;
+    int edge;              // edge_threshold
+    LevelInfo L[kMaxLevels];
+};
+
+// One candidate corner: level coordinates, FAST score, then Harris response and IC angle once computed.
+struct Cand {
+    uint16_t x, y;
+    uint8_t score, level;
+    uint16_t pad;
+    float harris;
+    float angle;
+};
+static_assert(sizeof(Cand) == 16, "Cand layout");
+
+// Resize coefficient of one destination column/row: source offset and the Q8 weight of the second sample.
+struct Coef {
+    int16_t ofs;
+    int16_t w1;
+};
+
+struct Tile {
+    int16_t level, pad;
+    int16_t x0, y0;
+};
+
+}  // namespace orbx

@@ -1,0 +1,611 @@
+// Descriptor matching on gfx950: brute-force Hamming (cv::BFMatcher replacement), the reference's
+// radius + mean-absolute-difference matcher, and the two projection ("windowed") matchers.
+// Reference: src/geometry/orb_matcher.cpp, include/orb_slam/geometry/orb_matcher.h:45-96,
+// src/frame.cpp:89-218, src/geometry/utils.cpp:184-236.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+using namespace orbx;
+
+namespace {
+
+constexpr unsigned long long kNoMatch = ~0ull;
+constexpr int kListCap = 2048;   // candidates of one search window
+constexpr int kMaxFeatures = 8192;  // features per frame the windowed matcher keeps flags for in LDS
+
+// K9: brute-force Hamming, one query per lane (8 dwords in registers), train descriptors staged through LDS in
+// tiles of 256 and broadcast to all lanes.  Packed (distance << 32 | train index) keys make the strict-less,
+// lowest-index-wins rule of cv::BFMatcher a plain minimum, so train chunks can be merged with atomicMin.
+__global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr,
+                                                    int nq_const, size_t q_stride, const uint8_t* __restrict__ t,
+                                                    const int* __restrict__ nt_arr, int nt_const, size_t t_stride,
+                                                    int chunk, unsigned long long* __restrict__ best,
+                                                    size_t best_stride) {
+    __shared__ uint4 tile[512];
+    const int p = blockIdx.z;
+    const int nq = nq_arr ? nq_arr[p] : nq_const;
+    const int nt = nt_arr ? nt_arr[p] : nt_const;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * chunk;
+    const int t1 = min(nt, t0 + chunk);
+    if (blockIdx.x * 256 >= nq || t0 >= t1) return;
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (qi < nq) {
+        const uint4* qp = (const uint4*)(q + (size_t)p * q_stride + (size_t)qi * 32);
+        qa = qp[0];
+        qb = qp[1];
+    }
+    const uint4* tp = (const uint4*)(t + (size_t)p * t_stride);
+    unsigned best_d = 0x7fffffffu;
+    int best_i = -1;
+    for (int tb = t0; tb < t1; tb += 256) {
+        __syncthreads();
+        const int j = tb + threadIdx.x;
+        if (j < t1) {
+            tile[2 * threadIdx.x] = tp[2 * (size_t)j];
+            tile[2 * threadIdx.x + 1] = tp[2 * (size_t)j + 1];
+        }
+        __syncthreads();
+        const int cnt = min(256, t1 - tb);
+        for (int k = 0; k < cnt; k++) {
+            const uint4 a = tile[2 * k], b = tile[2 * k + 1];
+            unsigned d = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
+                         __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
+            if (d < best_d) {
+                best_d = d;
+                best_i = tb + k;
+            }
+        }
+    }
+    if (qi < nq && best_i >= 0)
+        atomicMin(&best[(size_t)p * best_stride + qi], ((unsigned long long)best_d << 32) | (unsigned)best_i);
+}
+
+__global__ void k_unpack_best(const unsigned long long* __restrict__ best, size_t best_stride,
+                              const int* __restrict__ nq_arr, int nq_const, int32_t* __restrict__ idx,
+                              int32_t* __restrict__ dist, size_t out_stride) {
+    const int p = blockIdx.y;
+    const int nq = nq_arr ? nq_arr[p] : nq_const;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const unsigned long long k = best[(size_t)p * best_stride + i];
+    idx[(size_t)p * out_stride + i] = k == kNoMatch ? -1 : (int32_t)(k & 0xffffffffu);
+    dist[(size_t)p * out_stride + i] = k == kNoMatch ? -1 : (int32_t)(k >> 32);
+}
+
+// BruteForceWithRadiusMatcher (orb_matcher.cpp:25-74): sum of absolute byte differences (v_sad_u8) over reference
+// keypoints within the pixel radius; strict-less, first-wins, so the same packed-key minimum applies.
+__global__ __launch_bounds__(256) void k_bf_sad_radius(const uint8_t* __restrict__ q, const float2* __restrict__ qxy,
+                                                       int nq, const uint8_t* __restrict__ t,
+                                                       const float2* __restrict__ txy, int nt, int chunk,
+                                                       double max_sq, unsigned long long* __restrict__ best) {
+    __shared__ uint4 tile[512];
+    __shared__ float2 txy_s[256];
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * chunk;
+    const int t1 = min(nt, t0 + chunk);
+    if (t0 >= t1) return;
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    float2 qp = make_float2(0.f, 0.f);
+    if (qi < nq) {
+        const uint4* p = (const uint4*)(q + (size_t)qi * 32);
+        qa = p[0];
+        qb = p[1];
+        qp = qxy[qi];
+    }
+    const uint4* tp = (const uint4*)t;
+    unsigned best_d = 0x7fffffffu;
+    int best_i = -1;
+    for (int tb = t0; tb < t1; tb += 256) {
+        __syncthreads();
+        const int j = tb + threadIdx.x;
+        if (j < t1) {
+            tile[2 * threadIdx.x] = tp[2 * (size_t)j];
+            tile[2 * threadIdx.x + 1] = tp[2 * (size_t)j + 1];
+            txy_s[threadIdx.x] = txy[j];
+        }
+        __syncthreads();
+        const int cnt = min(256, t1 - tb);
+        for (int k = 0; k < cnt; k++) {
+            const float2 r = txy_s[k];
+            const float dx = r.x - qp.x, dy = r.y - qp.y;
+            const float sq = dx * dx + dy * dy;
+            if ((double)sq <= max_sq) {
+                const uint4 a = tile[2 * k], b = tile[2 * k + 1];
+                unsigned d = 0;
+                d = __builtin_amdgcn_sad_u8(qa.x, a.x, d);
+                d = __builtin_amdgcn_sad_u8(qa.y, a.y, d);
+                d = __builtin_amdgcn_sad_u8(qa.z, a.z, d);
+                d = __builtin_amdgcn_sad_u8(qa.w, a.w, d);
+                d = __builtin_amdgcn_sad_u8(qb.x, b.x, d);
+                d = __builtin_amdgcn_sad_u8(qb.y, b.y, d);
+                d = __builtin_amdgcn_sad_u8(qb.z, b.z, d);
+                d = __builtin_amdgcn_sad_u8(qb.w, b.w, d);
+                if (d < best_d) {
+                    best_d = d;
+                    best_i = tb + k;
+                }
+            }
+        }
+    }
+    if (qi < nq && best_i >= 0) atomicMin(&best[qi], ((unsigned long long)best_d << 32) | (unsigned)best_i);
+}
+
+struct ProjArgs {
+    orbx_grid g;
+    const int32_t* cell_start;
+    const int32_t* cell_items;
+    const orbx_keypoint* kps;   // frame features
+    int n;
+    const uint8_t* desc;        // frame descriptors
+    const orbx_keypoint* ref_kps;  // mode 0: reference features (octave, angle); mode 1: unused
+    int n_ref;
+    const uint8_t* ref_flag;    // mode 0: has map point; mode 1: in view
+    const float* proj_xy;
+    const float* proj_z;        // mode 0 only
+    const int32_t* pred_level;  // mode 1 only
+    const float* view_cos;      // mode 1 only
+    const uint8_t* ref_desc;
+    const float* scale_factors;
+    int n_levels;
+    int level_mode;
+    float radius;
+    float nn_ratio;
+    int check_orientation;
+    int32_t* matched;           // out [n]
+    int32_t* dists;             // out [n]
+    int32_t* pushes;            // scratch [n_ref * 2]: (bin, feature) of every histogram push
+    int32_t* status;            // out: 1 = a window held more than kListCap candidates
+};
+
+__device__ __forceinline__ int hamming32(const uint8_t* a, const uint8_t* b) {
+    const uint4* pa = (const uint4*)a;
+    const uint4* pb = (const uint4*)b;
+    const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// K10: projection matchers, one wavefront per frame.  Reference points are visited in order (the greedy
+// "already matched" rule of orb_matcher.cpp:216,313 makes the outer loop sequential); for each one the 64 lanes
+// gather the search window from the CSR bucket grid in the reference's cell-scan order (x-major cells, features in
+// index order inside a cell), compute the Hamming distances in parallel, and lane 0 resolves the ordered list.
+// MODE 0 = frame-to-frame (orb_matcher.cpp:115-255), MODE 1 = map points (orb_matcher.cpp:257-352).
+template <int MODE>
+__global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
+    extern __shared__ int32_t s_matched[];  // [n]
+    __shared__ int32_t s_idx[kListCap];
+    __shared__ int32_t s_dist[kListCap];
+    __shared__ int32_t s_hist[30];
+    const int lane = threadIdx.x;
+    const orbx_grid g = A.g;
+    for (int i = lane; i < A.n; i += 64) {
+        s_matched[i] = -1;
+        A.dists[i] = -1;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    __syncthreads();
+    int n_push = 0;
+    const float factor = 1.0f / 30;
+    for (int ref_idx = 0; ref_idx < A.n_ref; ++ref_idx) {
+        if (!A.ref_flag[ref_idx]) continue;
+        const float px = A.proj_xy[2 * ref_idx], py = A.proj_xy[2 * ref_idx + 1];
+        int level, min_level, max_level;
+        bool min_only = false;
+        float radius_scaled;
+        if (MODE == 0) {
+            if (A.proj_z[ref_idx] < 0) continue;
+            if (!(px > g.min_x && px < g.max_x && py > g.min_y && py < g.max_y)) continue;
+            level = A.ref_kps[ref_idx].octave;
+            if (level < 0 || level >= A.n_levels) continue;
+            radius_scaled = A.radius * A.scale_factors[level];
+            if (A.level_mode == 1) { min_level = level; max_level = 0x7fffffff; min_only = true; }
+            else if (A.level_mode == 2) { min_level = 0; max_level = level; }
+            else { min_level = level - 1; max_level = level + 1; }
+        } else {
+            level = A.pred_level[ref_idx];
+            if (level < 0 || level >= A.n_levels) continue;
+            const float by_cos = A.view_cos[ref_idx] > 0.998 ? 2.5f : 4.0f;
+            radius_scaled = A.radius * by_cos * A.scale_factors[level];
+            min_level = level - 1;
+            max_level = level;
+        }
+        // Frame::getBoxAroundPoint (frame.cpp:89-118)
+        const int left = max(0, (int)floorf(px - g.min_x - radius_scaled) / g.grid_size_x);
+        if (left >= g.grid_cols) continue;
+        const int right = min(g.grid_cols - 1, (int)ceilf(px - g.min_x + radius_scaled) / g.grid_size_x);
+        if (right < 0) continue;
+        const int up = max(0, (int)floorf(py - g.min_y - radius_scaled) / g.grid_size_y);
+        if (up >= g.grid_rows) continue;
+        const int down = min(g.grid_rows - 1, (int)ceilf(py - g.min_y + radius_scaled) / g.grid_size_y);
+        if (down < 0) continue;
+        const int ncy = down - up + 1;
+        const int ncells = (right - left + 1) * ncy;
+        // ordered gather of the window
+        int list_n = 0;
+        bool overflow = false;
+        for (int cbase = 0; cbase < ncells; cbase += 64) {
+            const int c = cbase + lane;
+            int cnt = 0, i0 = 0, i1 = 0, cxi = 0, cyi = 0;
+            if (c < ncells) {
+                cxi = left + c / ncy;
+                cyi = up + c % ncy;
+                const int cell = cxi * g.grid_rows + cyi;
+                i0 = A.cell_start[cell];
+                i1 = A.cell_start[cell + 1];
+            }
+            auto accept = [&](int idx) -> bool {
+                if (s_matched[idx] > 0) return false;
+                const orbx_keypoint k = A.kps[idx];
+                if (min_only) {
+                    // 4-argument overload (frame.cpp:151-183): distance to the CELL index, as the reference does
+                    if (k.octave < min_level) return false;
+                    return fabsf(k.x - (float)cxi) < radius_scaled && fabsf(k.y - (float)cyi) < radius_scaled;
+                }
+                if (k.octave < min_level || k.octave > max_level) return false;
+                return fabsf(k.x - px) < radius_scaled && fabsf(k.y - py) < radius_scaled;
+            };
+            for (int i = i0; i < i1; i++) cnt += accept(A.cell_items[i]) ? 1 : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int total = __shfl(incl, 63);
+            int pos = list_n + incl - cnt;
+            if (list_n + total > kListCap) overflow = true;
+            else
+                for (int i = i0; i < i1; i++) {
+                    const int idx = A.cell_items[i];
+                    if (accept(idx)) s_idx[pos++] = idx;
+                }
+            if (overflow) break;
+            list_n += total;
+        }
+        if (overflow) {
+            if (lane == 0) *A.status = 1;
+            break;
+        }
+        __syncthreads();
+        const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
+        for (int i = lane; i < list_n; i += 64) s_dist[i] = hamming32(rd, A.desc + (size_t)s_idx[i] * 32);
+        __syncthreads();
+        if (lane == 0 && list_n > 0) {
+            if (MODE == 0) {
+                int min_d = 256, id = -1;
+                for (int i = 0; i < list_n; i++)
+                    if (s_dist[i] <= min_d) { min_d = s_dist[i]; id = s_idx[i]; }
+                if (min_d <= 100 && id >= 0) {
+                    s_matched[id] = ref_idx;
+                    A.dists[id] = min_d;
+                    if (A.check_orientation) {
+                        float rot = A.ref_kps[ref_idx].angle - A.kps[id].angle;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == 30) bin = 0;
+                        if (bin >= 0 && bin < 30) {
+                            s_hist[bin]++;
+                            A.pushes[2 * n_push] = bin;
+                            A.pushes[2 * n_push + 1] = id;
+                            n_push++;
+                        }
+                    }
+                }
+            } else {
+                int min_d = 256, id1 = -1, min2 = 256, id2 = -1;
+                for (int i = 0; i < list_n; i++) {
+                    const int d = s_dist[i], idx = s_idx[i];
+                    if (d < min_d) { min2 = min_d; id2 = id1; min_d = d; id1 = idx; }
+                    else if (d < min2) { min2 = d; id2 = idx; }
+                    if (min_d <= 100) {
+                        // no second candidate yet: the reference reads key_points[-1]; treated as "octaves differ"
+                        if (id2 >= 0 && A.kps[id1].octave == A.kps[id2].octave && (float)min_d > A.nn_ratio * (float)min2)
+                            continue;
+                        s_matched[id1] = ref_idx;
+                        A.dists[id1] = min_d;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (MODE == 0 && A.check_orientation) {
+        // MatcherBase::applyRotationConstraint + computeThreeMaxima (orb_matcher.h:57-79, utils.cpp:202-236)
+        n_push = __shfl(n_push, 0);
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = lane; i < n_push; i += 64) {
+            const int bin = A.pushes[2 * i];
+            if (bin != ind1 && bin != ind2 && bin != ind3) s_matched[A.pushes[2 * i + 1]] = 0;
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < A.n; i += 64) A.matched[i] = s_matched[i];
+}
+
+}  // namespace
+
+struct orbx_matcher {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DevBuf<uint8_t> d_q, d_t, d_flags;
+    DevBuf<unsigned long long> d_best;
+    DevBuf<int32_t> d_idx, d_dist, d_ints, d_cells, d_items, d_pushes;
+    DevBuf<float> d_f0, d_f1, d_f2;
+    DevBuf<orbx_keypoint> d_kp, d_refkp;
+    std::vector<unsigned long long> h_best;
+};
+
+namespace {
+
+int pick_chunk(int n_train, int q_blocks, int pairs) {
+    // enough workgroups to cover the chip: split the train set when queries x pairs alone cannot
+    int want = 1024;
+    int have = std::max(1, q_blocks * pairs);
+    int chunks = std::min(std::max(1, want / have), std::max(1, n_train / 256));
+    int chunk = div_up(std::max(n_train, 1), chunks);
+    return div_up(chunk, 256) * 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+orbx_status orbx_matcher_create(int device, orbx_matcher** out) {
+    if (!out) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(device));
+    orbx_matcher* h = new orbx_matcher();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return ORBX_DEVICE;
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_matcher_destroy(orbx_matcher* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    h->d_q.release(); h->d_t.release(); h->d_flags.release(); h->d_best.release(); h->d_idx.release();
+    h->d_dist.release(); h->d_ints.release(); h->d_cells.release(); h->d_items.release(); h->d_pushes.release();
+    h->d_f0.release(); h->d_f1.release(); h->d_f2.release(); h->d_kp.release(); h->d_refkp.release();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+orbx_status orbx_matcher_set_stream(orbx_matcher* h, void* hip_stream) {
+    if (!h) return ORBX_BAD_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return ORBX_OK;
+}
+
+orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, const int32_t* d_n_query,
+                                     size_t query_stride, const uint8_t* d_train, const int32_t* d_n_train,
+                                     size_t train_stride, int n_pairs, int max_query, int max_train,
+                                     int32_t* d_train_idx, int32_t* d_distance, size_t out_stride) {
+    if (!h || !d_query || !d_train || !d_train_idx || !d_distance) return ORBX_BAD_ARG;
+    if (n_pairs <= 0 || max_query < 0 || max_train < 0 || out_stride < (size_t)max_query) return ORBX_BAD_ARG;
+    if (max_query == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    size_t nb = (size_t)n_pairs * max_query;
+    ORBX_TRY(h->d_best.ensure(nb));
+    ORBX_HIP(hipMemsetAsync(h->d_best.p, 0xff, nb * sizeof(unsigned long long), s));
+    const int qb = div_up(max_query, 256);
+    if (max_train > 0) {
+        const int chunk = pick_chunk(max_train, qb, n_pairs);
+        dim3 grid(qb, div_up(max_train, chunk), n_pairs);
+        hipLaunchKernelGGL(k_bf_hamming, grid, dim3(256), 0, s, d_query, d_n_query, max_query, query_stride, d_train,
+                           d_n_train, max_train, train_stride, chunk, h->d_best.p, (size_t)max_query);
+    }
+    hipLaunchKernelGGL(k_unpack_best, dim3(qb, n_pairs), dim3(256), 0, s, h->d_best.p, (size_t)max_query, d_n_query,
+                       max_query, d_train_idx, d_distance, out_stride);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+orbx_status orbx_match_hamming(orbx_matcher* h, const uint8_t* query, int n_query, const uint8_t* train, int n_train,
+                               int32_t* train_idx, int32_t* distance) {
+    if (!h || n_query < 0 || n_train < 0) return ORBX_BAD_ARG;
+    if (n_query == 0) return ORBX_OK;
+    if (!query || !train_idx || !distance || (n_train > 0 && !train)) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_q.ensure((size_t)n_query * 32));
+    ORBX_TRY(h->d_t.ensure((size_t)std::max(n_train, 1) * 32));
+    ORBX_TRY(h->d_idx.ensure(n_query));
+    ORBX_TRY(h->d_dist.ensure(n_query));
+    ORBX_HIP(hipMemcpyAsync(h->d_q.p, query, (size_t)n_query * 32, hipMemcpyHostToDevice, s));
+    if (n_train) ORBX_HIP(hipMemcpyAsync(h->d_t.p, train, (size_t)n_train * 32, hipMemcpyHostToDevice, s));
+    ORBX_TRY(orbx_match_hamming_batch(h, h->d_q.p, nullptr, 0, h->d_t.p, nullptr, 0, 1, n_query, n_train, h->d_idx.p,
+                                      h->d_dist.p, n_query));
+    ORBX_HIP(hipMemcpyAsync(train_idx, h->d_idx.p, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(distance, h->d_dist.p, sizeof(int32_t) * n_query, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+orbx_status orbx_match_radius(orbx_matcher* h, const orbx_keypoint* kp, int n, const orbx_keypoint* ref_kp, int n_ref,
+                              const uint8_t* desc, const uint8_t* ref_desc, double max_pixel_dist, orbx_match* matches,
+                              int* count) {
+    if (!h || !count || n < 0 || n_ref < 0) return ORBX_BAD_ARG;
+    *count = 0;
+    if (n == 0 || n_ref == 0) return ORBX_OK;
+    if (!kp || !ref_kp || !desc || !ref_desc || !matches) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    std::vector<float> xy(2 * (size_t)n), rxy(2 * (size_t)n_ref);
+    for (int i = 0; i < n; i++) { xy[2 * i] = kp[i].x; xy[2 * i + 1] = kp[i].y; }
+    for (int i = 0; i < n_ref; i++) { rxy[2 * i] = ref_kp[i].x; rxy[2 * i + 1] = ref_kp[i].y; }
+    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
+    ORBX_TRY(h->d_t.ensure((size_t)n_ref * 32));
+    ORBX_TRY(h->d_f0.ensure(xy.size()));
+    ORBX_TRY(h->d_f1.ensure(rxy.size()));
+    ORBX_TRY(h->d_best.ensure(n));
+    ORBX_HIP(hipMemcpyAsync(h->d_q.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_t.p, ref_desc, (size_t)n_ref * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f0.p, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f1.p, rxy.data(), rxy.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemsetAsync(h->d_best.p, 0xff, (size_t)n * sizeof(unsigned long long), s));
+    const int qb = div_up(n, 256);
+    const int chunk = pick_chunk(n_ref, qb, 1);
+    const double max_sq = max_pixel_dist * max_pixel_dist;
+    hipLaunchKernelGGL(k_bf_sad_radius, dim3(qb, div_up(n_ref, chunk)), dim3(256), 0, s, h->d_q.p,
+                       (const float2*)h->d_f0.p, n, h->d_t.p, (const float2*)h->d_f1.p, n_ref, chunk, max_sq,
+                       h->d_best.p);
+    ORBX_HIP(hipGetLastError());
+    h->h_best.resize(n);
+    ORBX_HIP(hipMemcpyAsync(h->h_best.data(), h->d_best.p, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    int c = 0;
+    for (int i = 0; i < n; i++) {
+        const unsigned long long k = h->h_best[i];
+        if (k == kNoMatch) continue;
+        const double feature_dist = (double)(unsigned)(k >> 32) / 32;  // cv::sum(diff)[0] / descriptors.cols
+        matches[c++] = orbx_match{i, (int32_t)(k & 0xffffffffu), -1, (float)feature_dist};
+    }
+    *count = c;
+    return ORBX_OK;
+}
+
+static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g, const int32_t* cell_start,
+                                  const int32_t* cell_items, const orbx_keypoint* kps, int n, const uint8_t* desc,
+                                  const orbx_keypoint* ref_kps, int n_ref, const uint8_t* flags, const float* proj_xy,
+                                  const float* proj_z, const int32_t* pred_level, const float* view_cos,
+                                  const uint8_t* ref_desc, const float* scale_factors, int n_levels, int level_mode,
+                                  float radius, float nn_ratio, int check_orientation, orbx_match* matches,
+                                  int* count) {
+    if (!h || !g || !count || n < 0 || n_ref < 0) return ORBX_BAD_ARG;
+    *count = 0;
+    if (n == 0 || n_ref == 0) return ORBX_OK;
+    if (!cell_start || !cell_items || !kps || !desc || !flags || !proj_xy || !ref_desc || !scale_factors || !matches)
+        return ORBX_BAD_ARG;
+    if (mode == 0 && (!ref_kps || !proj_z)) return ORBX_BAD_ARG;
+    if (mode == 1 && (!pred_level || !view_cos)) return ORBX_BAD_ARG;
+    if (g->grid_cols <= 0 || g->grid_rows <= 0 || g->grid_size_x <= 0 || g->grid_size_y <= 0 || n_levels <= 0)
+        return ORBX_BAD_ARG;
+    if (n > kMaxFeatures) return ORBX_CAPACITY;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int ncell = g->grid_cols * g->grid_rows;
+    ORBX_TRY(h->d_cells.ensure(ncell + 1));
+    ORBX_TRY(h->d_items.ensure(n));
+    ORBX_TRY(h->d_kp.ensure(n));
+    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
+    ORBX_TRY(h->d_t.ensure((size_t)n_ref * 32));
+    ORBX_TRY(h->d_flags.ensure(n_ref));
+    ORBX_TRY(h->d_f0.ensure((size_t)2 * n_ref));
+    ORBX_TRY(h->d_f1.ensure(n_ref));
+    ORBX_TRY(h->d_f2.ensure(n_levels));
+    ORBX_TRY(h->d_refkp.ensure(n_ref));
+    ORBX_TRY(h->d_ints.ensure(n_ref + 1));
+    ORBX_TRY(h->d_idx.ensure(n));
+    ORBX_TRY(h->d_dist.ensure(n));
+    ORBX_TRY(h->d_pushes.ensure((size_t)2 * n_ref + 2));
+    ORBX_HIP(hipMemcpyAsync(h->d_cells.p, cell_start, sizeof(int32_t) * (ncell + 1), hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_items.p, cell_items, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, kps, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_q.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_t.p, ref_desc, (size_t)n_ref * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_flags.p, flags, n_ref, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f0.p, proj_xy, sizeof(float) * 2 * n_ref, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_factors, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    if (mode == 0) {
+        ORBX_HIP(hipMemcpyAsync(h->d_f1.p, proj_z, sizeof(float) * n_ref, hipMemcpyHostToDevice, s));
+        ORBX_HIP(hipMemcpyAsync(h->d_refkp.p, ref_kps, sizeof(orbx_keypoint) * n_ref, hipMemcpyHostToDevice, s));
+    } else {
+        ORBX_HIP(hipMemcpyAsync(h->d_f1.p, view_cos, sizeof(float) * n_ref, hipMemcpyHostToDevice, s));
+        ORBX_HIP(hipMemcpyAsync(h->d_ints.p, pred_level, sizeof(int32_t) * n_ref, hipMemcpyHostToDevice, s));
+    }
+    int32_t* d_status = h->d_ints.p + n_ref;
+    ORBX_HIP(hipMemsetAsync(d_status, 0, sizeof(int32_t), s));
+    // host-side validation of what the kernel indexes with: CSR offsets and items
+    if (cell_start[0] != 0 || cell_start[ncell] != n) return ORBX_BAD_ARG;
+    for (int c = 0; c < ncell; c++)
+        if (cell_start[c + 1] < cell_start[c]) return ORBX_BAD_ARG;
+    for (int i = 0; i < n; i++)
+        if (cell_items[i] < 0 || cell_items[i] >= n) return ORBX_BAD_ARG;
+
+    ProjArgs A;
+    A.g = *g;
+    A.cell_start = h->d_cells.p;
+    A.cell_items = h->d_items.p;
+    A.kps = h->d_kp.p;
+    A.n = n;
+    A.desc = h->d_q.p;
+    A.ref_kps = h->d_refkp.p;
+    A.n_ref = n_ref;
+    A.ref_flag = h->d_flags.p;
+    A.proj_xy = h->d_f0.p;
+    A.proj_z = h->d_f1.p;
+    A.pred_level = h->d_ints.p;
+    A.view_cos = h->d_f1.p;
+    A.ref_desc = h->d_t.p;
+    A.scale_factors = h->d_f2.p;
+    A.n_levels = n_levels;
+    A.level_mode = level_mode;
+    A.radius = radius;
+    A.nn_ratio = nn_ratio;
+    A.check_orientation = check_orientation;
+    A.matched = h->d_idx.p;
+    A.dists = h->d_dist.p;
+    A.pushes = h->d_pushes.p;
+    A.status = d_status;
+    const size_t shmem = sizeof(int32_t) * (size_t)n;
+    if (mode == 0) hipLaunchKernelGGL(k_projection_match<0>, dim3(1), dim3(64), shmem, s, A);
+    else hipLaunchKernelGGL(k_projection_match<1>, dim3(1), dim3(64), shmem, s, A);
+    ORBX_HIP(hipGetLastError());
+    std::vector<int32_t> matched(n), dists(n);
+    int32_t status = 0;
+    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(&status, d_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    if (status != 0) return ORBX_CAPACITY;
+    // MatcherBase::createMatches (orb_matcher.h:81-93)
+    int c = 0;
+    for (int i = 0; i < n; i++)
+        if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
+    *count = c;
+    return ORBX_OK;
+}
+
+orbx_status orbx_match_projection_frame(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,
+                                        const int32_t* cell_items, const orbx_keypoint* keypoints, int n,
+                                        const uint8_t* descriptors, const orbx_keypoint* ref_keypoints, int n_ref,
+                                        const uint8_t* ref_has_point, const float* proj_xy, const float* proj_z,
+                                        const uint8_t* ref_descriptors, const float* scale_factors, int n_levels,
+                                        int level_mode, float radius, int check_orientation, orbx_match* matches,
+                                        int* count) {
+    return run_projection(h, 0, g, cell_start, cell_items, keypoints, n, descriptors, ref_keypoints, n_ref,
+                          ref_has_point, proj_xy, proj_z, nullptr, nullptr, ref_descriptors, scale_factors, n_levels,
+                          level_mode, radius, 0.f, check_orientation, matches, count);
+}
+
+orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,
+                                         const int32_t* cell_items, const orbx_keypoint* keypoints, int n,
+                                         const uint8_t* descriptors, int n_points, const uint8_t* in_view,
+                                         const float* proj_xy, const int32_t* pred_level, const float* view_cos,
+                                         const uint8_t* point_descriptors, const float* scale_factors, int n_levels,
+                                         float radius, float nn_ratio, orbx_match* matches, int* count) {
+    return run_projection(h, 1, g, cell_start, cell_items, keypoints, n, descriptors, nullptr, n_points, in_view,
+                          proj_xy, nullptr, pred_level, view_cos, point_descriptors, scale_factors, n_levels, 0,
+                          radius, nn_ratio, 0, matches, count);
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// Two-view F/H RANSAC behind orbx_ransac_fh / orbx_ransac_fh_batch.
+// Replaces Initializer::findFundamentalAndHomography and its callees (reference src/Initializer.cpp:254-585,
+// src/geometry/utils.cpp:18-154).
+#include <algorithm>
+
+#include "common.h"
+#include "ransac_kernels.h"
+
+using namespace orbx;
+
+namespace {
+enum Stage { RT_NORMALIZE = 0, RT_SOLVE, RT_SCORE_F, RT_SCORE_H, RT_SELECT, RT_COUNT };
+}
+
+struct orbx_ransac {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    DevBuf<float> d_pts, d_ref, d_pn, d_rn, d_T, d_Fall, d_Hall, d_Hiall, d_sf, d_sh, d_F, d_H, d_scores;
+    DevBuf<uint32_t> d_sets;
+    DevBuf<uint8_t> d_inlf, d_inlh;
+    DevBuf<int32_t> d_best;
+    StageTimer timer;
+    float last_ms[RT_COUNT] = {};
+};
+
+namespace {
+
+orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref, int n, const uint32_t* d_sets8,
+                      int iterations, int pairs, double sigma, float* d_F, float* d_H, uint8_t* d_inl_f,
+                      uint8_t* d_inl_h, float* d_scores, int32_t* d_best) {
+    hipStream_t s = h->stream;
+    const size_t pn = (size_t)pairs * n * 2, hyp = (size_t)pairs * iterations;
+    ORBX_TRY(h->d_pn.ensure(pn));
+    ORBX_TRY(h->d_rn.ensure(pn));
+    ORBX_TRY(h->d_T.ensure((size_t)pairs * 18));
+    ORBX_TRY(h->d_Fall.ensure(hyp * 9));
+    ORBX_TRY(h->d_Hall.ensure(hyp * 9));
+    ORBX_TRY(h->d_Hiall.ensure(hyp * 9));
+    ORBX_TRY(h->d_sf.ensure(hyp));
+    ORBX_TRY(h->d_sh.ensure(hyp));
+    StageTimer& T = h->timer;
+    T.clear();
+    T.begin(RT_NORMALIZE, s);
+    hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, h->d_pn.p, h->d_rn.p, h->d_T.p);
+    T.end(RT_NORMALIZE, s);
+    T.begin(RT_SOLVE, s);
+    hipLaunchKernelGGL(k_solve, dim3(div_up(iterations, 64), pairs), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p,
+                       d_sets8, iterations, h->d_Fall.p, h->d_Hall.p, h->d_Hiall.p);
+    T.end(RT_SOLVE, s);
+    T.begin(RT_SCORE_F, s);
+    hipLaunchKernelGGL(k_score_f, dim3(div_up(iterations, 256), pairs), dim3(256), 0, s, d_points, d_ref, n,
+                       h->d_Fall.p, iterations, sigma, h->d_sf.p);
+    T.end(RT_SCORE_F, s);
+    T.begin(RT_SCORE_H, s);
+    hipLaunchKernelGGL(k_score_h, dim3(div_up(iterations, 256), pairs), dim3(256), 0, s, d_points, d_ref, n,
+                       h->d_Hall.p, h->d_Hiall.p, iterations, sigma, h->d_sh.p);
+    T.end(RT_SCORE_H, s);
+    T.begin(RT_SELECT, s);
+    hipLaunchKernelGGL(k_select, dim3(pairs, 2), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, h->d_Hall.p,
+                       h->d_Hiall.p, h->d_sf.p, h->d_sh.p, iterations, sigma, d_F, d_H, d_inl_f, d_inl_h, d_scores,
+                       d_best);
+    T.end(RT_SELECT, s);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+orbx_status check_sets(const uint32_t* sets8, int iterations, int n) {
+    for (size_t i = 0; i < (size_t)iterations * 8; i++)
+        if (sets8[i] >= (uint32_t)n) return ORBX_BAD_ARG;
+    return ORBX_OK;
+}
+
+orbx_status upload_pair(orbx_ransac* h, const float* points, const float* ref_points, int n, const uint32_t* sets8,
+                        int iterations) {
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_pts.ensure((size_t)n * 2));
+    ORBX_TRY(h->d_ref.ensure((size_t)n * 2));
+    ORBX_TRY(h->d_sets.ensure((size_t)iterations * 8));
+    ORBX_HIP(hipMemcpyAsync(h->d_pts.p, points, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_ref.p, ref_points, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_sets.p, sets8, sizeof(uint32_t) * 8 * iterations, hipMemcpyHostToDevice, s));
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+orbx_status orbx_ransac_create(int device, orbx_ransac** out) {
+    if (!out) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(device));
+    orbx_ransac* h = new orbx_ransac();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return ORBX_DEVICE;
+    }
+    h->stream = h->own_stream;
+    orbx_status st = h->timer.init();
+    if (st != ORBX_OK) {
+        orbx_ransac_destroy(h);
+        return st;
+    }
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_ransac_destroy(orbx_ransac* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    h->d_pts.release(); h->d_ref.release(); h->d_pn.release(); h->d_rn.release(); h->d_T.release();
+    h->d_Fall.release(); h->d_Hall.release(); h->d_Hiall.release(); h->d_sf.release(); h->d_sh.release();
+    h->d_F.release(); h->d_H.release(); h->d_scores.release(); h->d_sets.release(); h->d_inlf.release();
+    h->d_inlh.release(); h->d_best.release();
+    h->timer.destroy();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+orbx_status orbx_ransac_set_stream(orbx_ransac* h, void* hip_stream) {
+    if (!h) return ORBX_BAD_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return ORBX_OK;
+}
+
+int orbx_ransac_last_timings(const orbx_ransac* hc, float* ms, int cap) {
+    orbx_ransac* h = const_cast<orbx_ransac*>(hc);
+    if (!h || !ms) return 0;
+    int n = std::min(cap, (int)RT_COUNT);
+    for (int i = 0; i < n; i++) ms[i] = h->timer.ms(i);
+    return n;
+}
+
+orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const float* d_ref_points, int n,
+                                 const uint32_t* d_sets8, int iterations, int n_pairs, double sigma, float* d_F,
+                                 float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h, float* d_scores,
+                                 int32_t* d_best_iteration) {
+    if (!h || !d_points || !d_ref_points || !d_sets8 || !d_F || !d_H || !d_inliers_f || !d_inliers_h || !d_scores ||
+        !d_best_iteration)
+        return ORBX_BAD_ARG;
+    if (n < 8 || iterations <= 0 || n_pairs <= 0 || !(sigma > 0)) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    return run_batch(h, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H, d_inliers_f,
+                     d_inliers_h, d_scores, d_best_iteration);
+}
+
+orbx_status orbx_ransac_fh(orbx_ransac* h, const float* points, const float* ref_points, int n, const uint32_t* sets8,
+                           int iterations, double sigma, float* F, float* H, uint8_t* inliers_f, uint8_t* inliers_h,
+                           double* score_f, double* score_h, int32_t* best_iteration) {
+    if (!h || !points || !ref_points || !sets8 || !F || !H || !inliers_f || !inliers_h || !score_f || !score_h ||
+        !best_iteration)
+        return ORBX_BAD_ARG;
+    if (n < 8 || iterations <= 0 || !(sigma > 0)) return ORBX_BAD_ARG;
+    ORBX_TRY(check_sets(sets8, iterations, n));
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(upload_pair(h, points, ref_points, n, sets8, iterations));
+    ORBX_TRY(h->d_F.ensure(9));
+    ORBX_TRY(h->d_H.ensure(9));
+    ORBX_TRY(h->d_inlf.ensure(n));
+    ORBX_TRY(h->d_inlh.ensure(n));
+    ORBX_TRY(h->d_scores.ensure(2));
+    ORBX_TRY(h->d_best.ensure(2));
+    ORBX_TRY(run_batch(h, h->d_pts.p, h->d_ref.p, n, h->d_sets.p, iterations, 1, sigma, h->d_F.p, h->d_H.p,
+                       h->d_inlf.p, h->d_inlh.p, h->d_scores.p, h->d_best.p));
+    float hF[9], hH[9], sc[2];
+    int32_t best[2];
+    ORBX_HIP(hipMemcpyAsync(hF, h->d_F.p, sizeof(hF), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(hH, h->d_H.p, sizeof(hH), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(sc, h->d_scores.p, sizeof(sc), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(best, h->d_best.p, sizeof(best), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(inliers_f, h->d_inlf.p, n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(inliers_h, h->d_inlh.p, n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    if (best[0] >= 0) std::memcpy(F, hF, sizeof(hF));
+    if (best[1] >= 0) std::memcpy(H, hH, sizeof(hH));
+    *score_f = sc[0];
+    *score_h = sc[1];
+    best_iteration[0] = best[0];
+    best_iteration[1] = best[1];
+    return ORBX_OK;
+}
+
+orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float* ref_points, int n,
+                               const uint32_t* sets8, int iterations, double sigma, float* F_all, float* H_all,
+                               float* Hinv_all, float* score_f, float* score_h) {
+    if (!h || !points || !ref_points || !sets8) return ORBX_BAD_ARG;
+    if (n < 8 || iterations <= 0 || !(sigma > 0)) return ORBX_BAD_ARG;
+    ORBX_TRY(check_sets(sets8, iterations, n));
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(upload_pair(h, points, ref_points, n, sets8, iterations));
+    ORBX_TRY(h->d_F.ensure(9));
+    ORBX_TRY(h->d_H.ensure(9));
+    ORBX_TRY(h->d_inlf.ensure(n));
+    ORBX_TRY(h->d_inlh.ensure(n));
+    ORBX_TRY(h->d_scores.ensure(2));
+    ORBX_TRY(h->d_best.ensure(2));
+    ORBX_TRY(run_batch(h, h->d_pts.p, h->d_ref.p, n, h->d_sets.p, iterations, 1, sigma, h->d_F.p, h->d_H.p,
+                       h->d_inlf.p, h->d_inlh.p, h->d_scores.p, h->d_best.p));
+    const size_t m = (size_t)iterations * 9 * sizeof(float);
+    if (F_all) ORBX_HIP(hipMemcpyAsync(F_all, h->d_Fall.p, m, hipMemcpyDeviceToHost, s));
+    if (H_all) ORBX_HIP(hipMemcpyAsync(H_all, h->d_Hall.p, m, hipMemcpyDeviceToHost, s));
+    if (Hinv_all) ORBX_HIP(hipMemcpyAsync(Hinv_all, h->d_Hiall.p, m, hipMemcpyDeviceToHost, s));
+    if (score_f) ORBX_HIP(hipMemcpyAsync(score_f, h->d_sf.p, sizeof(float) * iterations, hipMemcpyDeviceToHost, s));
+    if (score_h) ORBX_HIP(hipMemcpyAsync(score_h, h->d_sh.p, sizeof(float) * iterations, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,546 @@
+// Two-view RANSAC kernels (gfx950): point normalisation, 8-point F / DLT H hypothesis solve, and scoring of
+// every hypothesis against every correspondence.  One LANE owns one hypothesis, so every sum is accumulated in
+// the reference's own order (src/Initializer.cpp:369-585) and the results are bit-identical to the scalar
+// evaluation; parallelism comes from the iterations x pairs hypotheses in flight.
+// Must be compiled with -ffp-contract=off: the reference build does not fuse multiply-adds.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orbx {
+
+// IEEE double hypot with the evaluation order of glibc 2.35's generic (non-FMA) __hypot, which is what
+// cv::JacobiSVD's std::hypot resolves to on x86-64 Linux.
+__device__ __forceinline__ double hypot_kernel(double ax, double ay) {
+    double t1, t2;
+    double h = sqrt(ax * ax + ay * ay);
+    if (h <= 2.0 * ay) {
+        double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+
+__device__ __forceinline__ double hypot_f64(double x, double y) {
+    const double SCALE = 0x1p-600, LARGE_VAL = 0x1p+511, TINY_VAL = 0x1p-459, EPS = 0x1p-54;
+    if (!isfinite(x) || !isfinite(y)) {
+        if (isinf(x) || isinf(y)) return INFINITY;
+        return x + y;
+    }
+    x = fabs(x);
+    y = fabs(y);
+    double ax = x < y ? y : x;
+    double ay = x < y ? x : y;
+    if (ax > LARGE_VAL) {
+        if (ay <= ax * EPS) return ax + ay;
+        return hypot_kernel(ax * SCALE, ay * SCALE) / SCALE;
+    }
+    if (ay < TINY_VAL) {
+        if (ax >= ay / EPS) return ax + ay;
+        return hypot_kernel(ax / SCALE, ay / SCALE) * SCALE;
+    }
+    if (ax >= ay / EPS) return ax + ay;
+    return hypot_kernel(ax, ay);
+}
+
+// cv::JacobiSVDImpl_<float> (OpenCV 3.4 core/lapack.cpp): one-sided Jacobi on the N rows (length M) of At, with
+// the rotations accumulated in Vt (N x N).  The first N1 rows of At are turned into an orthonormal set: rows with
+// a vanishing singular value, and rows >= N, are synthesised from cv::RNG(0x12345678) and Gram-Schmidt, exactly as
+// OpenCV does (for the 8x9 system that synthesised 9th row IS the null vector the reference takes).
+// W receives the singular values (double, sorted descending).  COMPLETE = false skips the At completion when only
+// Vt is wanted.
+template <int M, int N, int N1, bool COMPLETE>
+__device__ void jacobi_svd(float* At, float* Vt, double* W) {
+    const double minval = 1.17549435082228750797e-38;  // FLT_MIN
+    const float eps = 1.1920928955078125e-7f * 2;      // FLT_EPSILON * 2
+    const int max_iter = M > 30 ? M : 30;
+    float c, s;
+    double sd;
+    for (int i = 0; i < N; i++) {
+        sd = 0;
+        for (int k = 0; k < M; k++) {
+            float t = At[i * M + k];
+            sd += (double)t * t;
+        }
+        W[i] = sd;
+        for (int k = 0; k < N; k++) Vt[i * N + k] = 0;
+        Vt[i * N + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++)
+            for (int j = i + 1; j < N; j++) {
+                float* Ai = At + i * M;
+                float* Aj = At + j * M;
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < M; k++) p += (double)Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt((double)a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = hypot_f64((double)p, beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = (float)sqrt(delta / gamma);
+                    c = (float)(p / (gamma * s * 2));
+                } else {
+                    c = (float)sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * c * 2));
+                }
+                a = b = 0;
+                for (int k = 0; k < M; k++) {
+                    float t0 = c * Ai[k] + s * Aj[k];
+                    float t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0;
+                    Aj[k] = t1;
+                    a += (double)t0 * t0;
+                    b += (double)t1 * t1;
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = true;
+                float* Vi = Vt + i * N;
+                float* Vj = Vt + j * N;
+                for (int k = 0; k < N; k++) {
+                    float t0 = c * Vi[k] + s * Vj[k];
+                    float t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0;
+                    Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < N; i++) {
+        sd = 0;
+        for (int k = 0; k < M; k++) {
+            float t = At[i * M + k];
+            sd += (double)t * t;
+        }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < N; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double tw = W[i]; W[i] = W[j]; W[j] = tw;
+            for (int k = 0; k < M; k++) { float t = At[i * M + k]; At[i * M + k] = At[j * M + k]; At[j * M + k] = t; }
+            for (int k = 0; k < N; k++) { float t = Vt[i * N + k]; Vt[i * N + k] = Vt[j * N + k]; Vt[j * N + k] = t; }
+        }
+    }
+    if (!COMPLETE) return;
+    unsigned long long rng = 0x12345678ull;
+    for (int i = 0; i < N1; i++) {
+        sd = i < N ? W[i] : 0;
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const float val0 = (float)(1. / M);
+            for (int k = 0; k < M; k++) {
+                rng = (unsigned long long)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
+                float val = ((unsigned)rng & 256) != 0 ? val0 : -val0;
+                At[i * M + k] = val;
+            }
+            for (int iter = 0; iter < 2; iter++) {
+                for (int j = 0; j < i; j++) {
+                    sd = 0;
+                    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[j * M + k];
+                    float asum = 0;
+                    for (int k = 0; k < M; k++) {
+                        float t = (float)(At[i * M + k] - sd * At[j * M + k]);
+                        At[i * M + k] = t;
+                        asum += fabsf(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (int k = 0; k < M; k++) At[i * M + k] *= asum;
+                }
+            }
+            sd = 0;
+            for (int k = 0; k < M; k++) {
+                float t = At[i * M + k];
+                sd += (double)t * t;
+            }
+            sd = sqrt(sd);
+        }
+        s = (float)(sd > minval ? 1 / sd : 0.);
+        for (int k = 0; k < M; k++) At[i * M + k] *= s;
+    }
+}
+
+// cv::gemm small-matrix path for 3x3 CV_32F without transpose flags: float dot products, left to right.
+__device__ __forceinline__ void mul33(const float* A, const float* B, float* C) {
+    float out[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    for (int i = 0; i < 9; i++) C[i] = out[i];
+}
+
+// cv::invert 3x3 CV_32F (DECOMP_LU closed form, double determinant and cofactors).
+__device__ __forceinline__ void inv33(const float* S, float* D) {
+    double d = (double)S[0] * ((double)S[4] * S[8] - (double)S[5] * S[7]) -
+               (double)S[1] * ((double)S[3] * S[8] - (double)S[5] * S[6]) +
+               (double)S[2] * ((double)S[3] * S[7] - (double)S[4] * S[6]);
+    if (d == 0) {
+        for (int i = 0; i < 9; i++) D[i] = 0.f;
+        return;
+    }
+    float t[9];
+    d = 1. / d;
+    t[0] = (float)(((double)S[4] * S[8] - (double)S[5] * S[7]) * d);
+    t[1] = (float)(((double)S[2] * S[7] - (double)S[1] * S[8]) * d);
+    t[2] = (float)(((double)S[1] * S[5] - (double)S[2] * S[4]) * d);
+    t[3] = (float)(((double)S[5] * S[6] - (double)S[3] * S[8]) * d);
+    t[4] = (float)(((double)S[0] * S[8] - (double)S[2] * S[6]) * d);
+    t[5] = (float)(((double)S[2] * S[3] - (double)S[0] * S[5]) * d);
+    t[6] = (float)(((double)S[3] * S[7] - (double)S[4] * S[6]) * d);
+    t[7] = (float)(((double)S[1] * S[6] - (double)S[0] * S[7]) * d);
+    t[8] = (float)(((double)S[0] * S[4] - (double)S[1] * S[3]) * d);
+    for (int i = 0; i < 9; i++) D[i] = t[i];
+}
+
+// `mat *= 1.0 / mat(2,2)` on CV_32F: convertTo with the factor narrowed to float, dst = src * a + 0.f.
+__device__ __forceinline__ void scale33(float* M, double alpha) {
+    const float a = (float)alpha;
+    for (int i = 0; i < 9; i++) M[i] = M[i] * a + 0.f;
+}
+
+// geometry::normalizePoints (reference src/geometry/utils.cpp:18-52) for one point set per wavefront.
+// The float coordinate sums and the double sum of distances are accumulated by lane 0 in index order; the
+// per-point arithmetic runs on all lanes.  Output: normalised points and T (row-major 3x3).
+__global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts, const float* __restrict__ ref, int n,
+                                                  float* __restrict__ pts_n, float* __restrict__ ref_n,
+                                                  float* __restrict__ T_all) {
+    __shared__ double s_norm[1024];
+    __shared__ double s_bcast[3];
+    const int pair = blockIdx.x, side = blockIdx.y, lane = threadIdx.x;
+    const float* in = (side == 0 ? pts : ref) + (size_t)pair * n * 2;
+    float* out = (side == 0 ? pts_n : ref_n) + (size_t)pair * n * 2;
+    if (lane == 0) {
+        float sx = 0.f, sy = 0.f;
+        for (int i = 0; i < n; i++) {
+            sx = sx + in[2 * i];
+            sy = sy + in[2 * i + 1];
+        }
+        const double n_inv = 1.0 / n;
+        s_bcast[0] = sx * n_inv;
+        s_bcast[1] = sy * n_inv;
+    }
+    __syncthreads();
+    const double mean_x = s_bcast[0], mean_y = s_bcast[1];
+    double scale = 0.0;
+    for (int base = 0; base < n; base += 1024) {
+        const int cnt = min(1024, n - base);
+        for (int i = lane; i < cnt; i += 64) {
+            const float nx = (float)(in[2 * (base + i)] - mean_x), ny = (float)(in[2 * (base + i) + 1] - mean_y);
+            out[2 * (base + i)] = nx;
+            out[2 * (base + i) + 1] = ny;
+            s_norm[i] = sqrt((double)nx * nx + (double)ny * ny);
+        }
+        __syncthreads();
+        if (lane == 0)
+            for (int i = 0; i < cnt; i++) scale += s_norm[i];
+        __syncthreads();
+    }
+    if (lane == 0) {
+        scale *= 1.0 / n;
+        scale = sqrt(2.0) / scale;
+        s_bcast[2] = scale;
+    }
+    __syncthreads();
+    scale = s_bcast[2];
+    for (int i = lane; i < n; i += 64) {
+        out[2 * i] = (float)(out[2 * i] * scale);
+        out[2 * i + 1] = (float)(out[2 * i + 1] * scale);
+    }
+    if (lane == 0) {
+        float* T = T_all + ((size_t)pair * 2 + side) * 9;
+        T[0] = (float)scale; T[1] = 0.f; T[2] = (float)(-mean_x * scale);
+        T[3] = 0.f; T[4] = (float)scale; T[5] = (float)(-mean_y * scale);
+        T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;
+    }
+}
+
+// K11: one hypothesis per lane.  geometry::computeFundamentalMat (utils.cpp:61-103) and computeHomographyMat
+// (utils.cpp:112-154) on the 8 normalised correspondences of the set, then the de-normalisation and scaling of
+// Initializer::findFundamentalMat / findHomographyMat (Initializer.cpp:336-345, 476-486).
+__global__ __launch_bounds__(64) void k_solve(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
+                                              const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
+                                              int iterations, float* __restrict__ F_all, float* __restrict__ H_all,
+                                              float* __restrict__ Hinv_all) {
+    const int it = blockIdx.x * 64 + threadIdx.x;
+    const int pair = blockIdx.y;
+    if (it >= iterations) return;
+    const float* pn = pts_n + (size_t)pair * n * 2;
+    const float* rn = ref_n + (size_t)pair * n * 2;
+    const uint32_t* set = sets8 + ((size_t)pair * iterations + it) * 8;
+    float u1[8], v1[8], u2[8], v2[8];
+    for (int j = 0; j < 8; j++) {
+        const uint32_t idx = set[j];
+        u2[j] = pn[2 * idx];
+        v2[j] = pn[2 * idx + 1];
+        u1[j] = rn[2 * idx];
+        v1[j] = rn[2 * idx + 1];
+    }
+    const float* T = T_all + (size_t)pair * 18;
+    const float* refT = T + 9;
+    float At[144];
+    float Vt[81];
+    double W[9];
+    const size_t o = ((size_t)pair * iterations + it) * 9;
+    {
+        // 8x9 system used as is (rows = equations): N = 8 rows of length M = 9, completed to 9 rows
+        for (int i = 0; i < 8; i++) {
+            float* r = At + i * 9;
+            r[0] = u2[i] * u1[i]; r[1] = u2[i] * v1[i]; r[2] = u2[i];
+            r[3] = v2[i] * u1[i]; r[4] = v2[i] * v1[i]; r[5] = v2[i];
+            r[6] = u1[i]; r[7] = v1[i]; r[8] = 1;
+        }
+        jacobi_svd<9, 8, 9, true>(At, Vt, W);
+        // Fpre = vt.row(8) reshaped 3x3; second SVD works on its transpose
+        float Fpre[9], B[9], V3[9];
+        double W3[3];
+        for (int k = 0; k < 9; k++) Fpre[k] = At[8 * 9 + k];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) B[j * 3 + i] = Fpre[i * 3 + j];
+        jacobi_svd<3, 3, 3, true>(B, V3, W3);
+        float w0 = (float)W3[0], w1 = (float)W3[1];
+        float U[9], D[9] = {w0, 0, 0, 0, w1, 0, 0, 0, 0.f}, UD[9], Fn[9], tmp[9], Tt[9], F[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) U[j * 3 + i] = B[i * 3 + j];
+        mul33(U, D, UD);
+        mul33(UD, V3, Fn);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Tt[j * 3 + i] = T[i * 3 + j];
+        mul33(Tt, Fn, tmp);
+        mul33(tmp, refT, F);
+        if (fabs((double)F[8]) > 1e-8) scale33(F, 1.0 / F[8]);
+        for (int k = 0; k < 9; k++) F_all[o + k] = F[k];
+    }
+    {
+        // 16x9 system is transposed: N = 9 rows of length M = 16; only Vt is needed
+        for (int i = 0; i < 8; i++) {
+            const int c0 = 2 * i, c1 = 2 * i + 1;
+            At[0 * 16 + c0] = 0.0f; At[1 * 16 + c0] = 0.0f; At[2 * 16 + c0] = 0.0f;
+            At[3 * 16 + c0] = -u1[i]; At[4 * 16 + c0] = -v1[i]; At[5 * 16 + c0] = -1;
+            At[6 * 16 + c0] = v2[i] * u1[i]; At[7 * 16 + c0] = v2[i] * v1[i]; At[8 * 16 + c0] = v2[i];
+            At[0 * 16 + c1] = u1[i]; At[1 * 16 + c1] = v1[i]; At[2 * 16 + c1] = 1;
+            At[3 * 16 + c1] = 0.0f; At[4 * 16 + c1] = 0.0f; At[5 * 16 + c1] = 0.0f;
+            At[6 * 16 + c1] = -u2[i] * u1[i]; At[7 * 16 + c1] = -u2[i] * v1[i]; At[8 * 16 + c1] = -u2[i];
+        }
+        jacobi_svd<16, 9, 9, false>(At, Vt, W);
+        float Hn[9], Tinv[9], tmp[9], H[9], Hinv[9];
+        for (int k = 0; k < 9; k++) Hn[k] = Vt[8 * 9 + k];
+        inv33(T, Tinv);
+        mul33(Tinv, Hn, tmp);
+        mul33(tmp, refT, H);
+        inv33(H, Hinv);
+        if (fabs((double)H[8]) > 1e-8) scale33(H, 1.0 / H[8]);
+        for (int k = 0; k < 9; k++) {
+            H_all[o + k] = H[k];
+            Hinv_all[o + k] = Hinv[k];
+        }
+    }
+}
+
+constexpr int kScoreChunk = 2048;  // correspondences staged in LDS at a time (32 KB)
+
+// K12F: Initializer::checkFundamentalScore (Initializer.cpp:369-444) for one hypothesis per lane; fp64.
+__global__ __launch_bounds__(256) void k_score_f(const float* __restrict__ pts, const float* __restrict__ ref, int n,
+                                                 const float* __restrict__ F_all, int iterations, double sigma,
+                                                 float* __restrict__ score_out) {
+    __shared__ float4 s_pt[kScoreChunk];
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    const int pair = blockIdx.y;
+    const bool live = it < iterations;
+    const float* Fp = F_all + ((size_t)pair * iterations + (live ? it : 0)) * 9;
+    const double f11 = Fp[0], f12 = Fp[1], f13 = Fp[2], f21 = Fp[3], f22 = Fp[4], f23 = Fp[5], f31 = Fp[6],
+                 f32 = Fp[7], f33 = Fp[8];
+    double score = 0;
+    const double th = 3.841, th_score = 5.991;
+    const double inv_sigma_square = 1.0 / (sigma * sigma);
+    const float2* p2 = (const float2*)(pts + (size_t)pair * n * 2);
+    const float2* r2 = (const float2*)(ref + (size_t)pair * n * 2);
+    for (int base = 0; base < n; base += kScoreChunk) {
+        const int cnt = min(kScoreChunk, n - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const float2 a = r2[base + i], b = p2[base + i];
+            s_pt[i] = make_float4(a.x, a.y, b.x, b.y);
+        }
+        __syncthreads();
+        if (live)
+            for (int i = 0; i < cnt; i++) {
+                const float4 q = s_pt[i];
+                const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
+                const double a2 = f11 * u1 + f12 * v1 + f13;
+                const double b2 = f21 * u1 + f22 * v1 + f23;
+                const double c2 = f31 * u1 + f32 * v1 + f33;
+                const double num2 = a2 * u2 + b2 * v2 + c2;
+                const double sd1 = num2 * num2 / (a2 * a2 + b2 * b2);
+                const double chi1 = sd1 * inv_sigma_square;
+                if (!(chi1 > th)) score += th_score - chi1;
+                const double a1 = f11 * u2 + f21 * v2 + f31;
+                const double b1 = f12 * u2 + f22 * v2 + f32;
+                const double c1 = f13 * u2 + f23 * v2 + f33;
+                const double num1 = a1 * u1 + b1 * v1 + c1;
+                const double sd2 = num1 * num1 / (a1 * a1 + b1 * b1);
+                const double chi2 = sd2 * inv_sigma_square;
+                if (!(chi2 > th)) score += th_score - chi2;
+            }
+    }
+    if (live) score_out[(size_t)pair * iterations + it] = (float)score;
+}
+
+// K12H: Initializer::checkHomographyScore (Initializer.cpp:501-585); fp32 with the double reciprocal of the
+// reference (`1.0 / (float expression)` narrowed to float).
+__global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, const float* __restrict__ ref, int n,
+                                                 const float* __restrict__ H_all, const float* __restrict__ Hinv_all,
+                                                 int iterations, double sigma, float* __restrict__ score_out) {
+    __shared__ float4 s_pt[kScoreChunk];
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    const int pair = blockIdx.y;
+    const bool live = it < iterations;
+    const float* Hp = H_all + ((size_t)pair * iterations + (live ? it : 0)) * 9;
+    const float* Ip = Hinv_all + ((size_t)pair * iterations + (live ? it : 0)) * 9;
+    const float h11 = Hp[0], h12 = Hp[1], h13 = Hp[2], h21 = Hp[3], h22 = Hp[4], h23 = Hp[5], h31 = Hp[6], h32 = Hp[7],
+                h33 = Hp[8];
+    const float i11 = Ip[0], i12 = Ip[1], i13 = Ip[2], i21 = Ip[3], i22 = Ip[4], i23 = Ip[5], i31 = Ip[6], i32 = Ip[7],
+                i33 = Ip[8];
+    float score = 0;
+    const float th = 5.991;
+    const float invSigmaSquare = 1.0 / (sigma * sigma);
+    const float2* p2 = (const float2*)(pts + (size_t)pair * n * 2);
+    const float2* r2 = (const float2*)(ref + (size_t)pair * n * 2);
+    for (int base = 0; base < n; base += kScoreChunk) {
+        const int cnt = min(kScoreChunk, n - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const float2 a = r2[base + i], b = p2[base + i];
+            s_pt[i] = make_float4(a.x, a.y, b.x, b.y);
+        }
+        __syncthreads();
+        if (live)
+            for (int i = 0; i < cnt; i++) {
+                const float4 q = s_pt[i];
+                const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
+                const float w2in1inv = 1.0 / (i31 * u2 + i32 * v2 + i33);
+                const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
+                const float v2in1 = (i21 * u2 + i22 * v2 + i23) * w2in1inv;
+                const float sq1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+                const float chi1 = sq1 * invSigmaSquare;
+                if (!(chi1 > th)) score += th - chi1;
+                const float w1in2inv = 1.0 / (h31 * u1 + h32 * v1 + h33);
+                const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
+                const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
+                const float sq2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
+                const float chi2 = sq2 * invSigmaSquare;
+                if (!(chi2 > th)) score += th - chi2;
+            }
+    }
+    if (live) score_out[(size_t)pair * iterations + it] = score;
+}
+
+// Winner selection and inlier flags.  The reference keeps a hypothesis when (float)score > best (strict), best
+// starting at 0: the winner is the earliest iteration that reaches the maximum, provided the maximum is > 0
+// (Initializer.cpp:318,347-355,458,488-497).  grid = (pairs, 2): y = 0 fundamental, y = 1 homography.
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ pts, const float* __restrict__ ref, int n,
+                                                const float* __restrict__ F_all, const float* __restrict__ H_all,
+                                                const float* __restrict__ Hinv_all,
+                                                const float* __restrict__ score_f, const float* __restrict__ score_h,
+                                                int iterations, double sigma, float* __restrict__ F_out,
+                                                float* __restrict__ H_out, uint8_t* __restrict__ inl_f,
+                                                uint8_t* __restrict__ inl_h, float* __restrict__ scores_out,
+                                                int32_t* __restrict__ best_out) {
+    __shared__ float s_val[256];
+    __shared__ int s_it[256];
+    const int pair = blockIdx.x, model = blockIdx.y, tid = threadIdx.x;
+    const float* sc = (model == 0 ? score_f : score_h) + (size_t)pair * iterations;
+    float bv = 0.f;
+    int bi = -1;
+    for (int i = tid; i < iterations; i += 256) {
+        const float v = sc[i];
+        if (v > bv) { bv = v; bi = i; }  // strict: the earliest of this thread's equal maxima stays
+    }
+    s_val[tid] = bv;
+    s_it[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float v2 = s_val[tid + o];
+            const int i2 = s_it[tid + o];
+            const float v1 = s_val[tid];
+            const int i1 = s_it[tid];
+            if (i2 >= 0 && (i1 < 0 || v2 > v1 || (v2 == v1 && i2 < i1))) { s_val[tid] = v2; s_it[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const int best = s_it[0];
+    const float best_score = s_val[0];
+    if (tid == 0) {
+        best_out[pair * 2 + model] = best;
+        scores_out[pair * 2 + model] = best >= 0 ? best_score : 0.f;
+    }
+    uint8_t* inl = (model == 0 ? inl_f : inl_h) + (size_t)pair * n;
+    if (best < 0) {
+        for (int i = tid; i < n; i += 256) inl[i] = 0;
+        return;
+    }
+    const float2* p2 = (const float2*)(pts + (size_t)pair * n * 2);
+    const float2* r2 = (const float2*)(ref + (size_t)pair * n * 2);
+    const size_t o = ((size_t)pair * iterations + best) * 9;
+    if (model == 0) {
+        const float* Fp = F_all + o;
+        if (tid < 9) F_out[(size_t)pair * 9 + tid] = Fp[tid];
+        const double f11 = Fp[0], f12 = Fp[1], f13 = Fp[2], f21 = Fp[3], f22 = Fp[4], f23 = Fp[5], f31 = Fp[6],
+                     f32 = Fp[7], f33 = Fp[8];
+        const double th = 3.841;
+        const double inv_sigma_square = 1.0 / (sigma * sigma);
+        for (int i = tid; i < n; i += 256) {
+            const float u1 = r2[i].x, v1 = r2[i].y, u2 = p2[i].x, v2 = p2[i].y;
+            bool good = true;
+            const double a2 = f11 * u1 + f12 * v1 + f13;
+            const double b2 = f21 * u1 + f22 * v1 + f23;
+            const double c2 = f31 * u1 + f32 * v1 + f33;
+            const double num2 = a2 * u2 + b2 * v2 + c2;
+            const double chi1 = num2 * num2 / (a2 * a2 + b2 * b2) * inv_sigma_square;
+            if (chi1 > th) good = false;
+            const double a1 = f11 * u2 + f21 * v2 + f31;
+            const double b1 = f12 * u2 + f22 * v2 + f32;
+            const double c1 = f13 * u2 + f23 * v2 + f33;
+            const double num1 = a1 * u1 + b1 * v1 + c1;
+            const double chi2 = num1 * num1 / (a1 * a1 + b1 * b1) * inv_sigma_square;
+            if (chi2 > th) good = false;
+            inl[i] = good;
+        }
+    } else {
+        const float* Hp = H_all + o;
+        const float* Ip = Hinv_all + o;
+        if (tid < 9) H_out[(size_t)pair * 9 + tid] = Hp[tid];
+        const float h11 = Hp[0], h12 = Hp[1], h13 = Hp[2], h21 = Hp[3], h22 = Hp[4], h23 = Hp[5], h31 = Hp[6],
+                    h32 = Hp[7], h33 = Hp[8];
+        const float i11 = Ip[0], i12 = Ip[1], i13 = Ip[2], i21 = Ip[3], i22 = Ip[4], i23 = Ip[5], i31 = Ip[6],
+                    i32 = Ip[7], i33 = Ip[8];
+        const float th = 5.991;
+        const float invSigmaSquare = 1.0 / (sigma * sigma);
+        for (int i = tid; i < n; i += 256) {
+            const float u1 = r2[i].x, v1 = r2[i].y, u2 = p2[i].x, v2 = p2[i].y;
+            bool good = true;
+            const float w2in1inv = 1.0 / (i31 * u2 + i32 * v2 + i33);
+            const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
+            const float v2in1 = (i21 * u2 + i22 * v2 + i23) * w2in1inv;
+            const float sq1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+            if (sq1 * invSigmaSquare > th) good = false;
+            const float w1in2inv = 1.0 / (h31 * u1 + h32 * v1 + h33);
+            const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
+            const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
+            const float sq2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
+            if (sq2 * invSigmaSquare > th) good = false;
+            inl[i] = good;
+        }
+    }
+}
+
+}  // namespace orbx

@@ -1,0 +1,378 @@
+"""ctypes binding of liborbx.so (the C ABI declared in include/orbx.h).
+
+This is plumbing for tests and bench.py: every compute call goes through the C ABI into the HIP kernels.
+There is no CPU fallback; a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+MATCH_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("img", "<i4"), ("distance", "<f4")])
+
+OK, BAD_ARG, CAPACITY, DEVICE, UNSUPPORTED = range(5)
+
+# every symbol include/orbx.h declares
+SYMBOLS = [
+    "orbx_status_string", "orbx_last_error", "orbx_device_count",
+    "orbx_extractor_create", "orbx_extractor_destroy", "orbx_extractor_scale_tables", "orbx_detect", "orbx_compute",
+    "orbx_extract_batch", "orbx_extractor_device_results", "orbx_extractor_layout", "orbx_extractor_read_plane",
+    "orbx_extractor_last_timings", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_match_hamming",
+    "orbx_match_hamming_batch", "orbx_filter_matches", "orbx_match_radius", "orbx_assign_grid",
+    "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
+    "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
+    "orbx_ransac_last_timings", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+]
+
+
+class ExtractorParams(C.Structure):
+    """orbx_extractor_params; defaults are ORBExtractor's (reference orb_extractor.h:29-37)."""
+    _fields_ = [("n_key_points", C.c_int32), ("scale_factor", C.c_float), ("level_pyramid", C.c_int32),
+                ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+                ("patch_size", C.c_int32), ("score_threshold", C.c_int32)]
+
+
+class Grid(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("grid_size_x", C.c_int32),
+                ("grid_size_y", C.c_int32)]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().orbx_status_string(status).decode()
+        detail = lib().orbx_last_error().decode()
+        super().__init__(f"{where}: {msg}" + (f" ({detail})" if detail and status == DEVICE else ""))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_slam_amd/csrc` "
+                              "(python -c 'import __graft_entry__ as g; g.build()')")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.orbx_status_string.restype = C.c_char_p
+        _lib.orbx_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            getattr(_lib, name)
+    return _lib
+
+
+def _check(status, where):
+    if status != OK:
+        raise OrbxError(status, where)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().orbx_device_count()
+
+
+def make_params(n_key_points=8000, scale_factor=1.2, level_pyramid=4, edge_threshold=31, first_level=0, wta_k=2,
+                patch_size=31, score_threshold=20):
+    return ExtractorParams(n_key_points, scale_factor, level_pyramid, edge_threshold, first_level, wta_k, patch_size,
+                           score_threshold)
+
+
+def _img(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    return img, w, h, w * ch, ch
+
+
+class Extractor:
+    """Handle over orbx_extractor (ORBExtractor of the reference)."""
+
+    def __init__(self, params=None, max_width=640, max_height=480, max_batch=1, device=0, **kw):
+        self.params = params or make_params(**kw)
+        self._h = C.c_void_p()
+        _check(lib().orbx_extractor_create(C.byref(self.params), max_width, max_height, max_batch, device,
+                                           C.byref(self._h)), "orbx_extractor_create")
+
+    def close(self):
+        if self._h:
+            lib().orbx_extractor_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().orbx_extractor_set_stream(self._h, C.c_void_p(stream_ptr)), "orbx_extractor_set_stream")
+
+    def scale_tables(self):
+        n = self.params.level_pyramid
+        arrs = [np.zeros(n, np.float32) for _ in range(4)]
+        lsf = C.c_float()
+        _check(lib().orbx_extractor_scale_tables(self._h, *[_p(a) for a in arrs], C.byref(lsf)), "scale_tables")
+        return (lsf.value, *arrs)
+
+    def layout(self, width, height):
+        n = self.params.level_pyramid
+        aw, ah = C.c_int(), C.c_int()
+        rects = np.zeros((n, 4), np.int32)
+        scales = np.zeros(n, np.float32)
+        _check(lib().orbx_extractor_layout(self._h, width, height, C.byref(aw), C.byref(ah), _p(rects), _p(scales)),
+               "orbx_extractor_layout")
+        return aw.value, ah.value, rects, scales
+
+    def read_plane(self, what, width, height, frame=0):
+        aw, ah, _, _ = self.layout(width, height)
+        out = np.zeros((ah, aw), np.uint8)
+        _check(lib().orbx_extractor_read_plane(self._h, frame, what, _p(out), out.nbytes), "orbx_extractor_read_plane")
+        return out
+
+    def detect(self, image, capacity=100000):
+        img, w, h, stride, ch = _img(image)
+        out = np.zeros(capacity, KP_DTYPE)
+        n = C.c_int()
+        _check(lib().orbx_detect(self._h, _p(img), w, h, stride, ch, _p(out), capacity, C.byref(n)), "orbx_detect")
+        return out[:n.value].copy()
+
+    def compute(self, image, keypoints):
+        img, w, h, stride, ch = _img(image)
+        k = np.ascontiguousarray(keypoints, KP_DTYPE).copy()
+        n = C.c_int(len(k))
+        desc = np.zeros((max(len(k), 1), 32), np.uint8)
+        _check(lib().orbx_compute(self._h, _p(img), w, h, stride, ch, _p(k), C.byref(n), _p(desc)), "orbx_compute")
+        return k[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, d_images_ptr, n_frames, frame_stride, width, height, stride, channels, capacity,
+                      to_host=True):
+        kps = np.zeros((n_frames, capacity), KP_DTYPE) if to_host else None
+        counts = np.zeros(n_frames, np.int32)
+        desc = np.zeros((n_frames, capacity, 32), np.uint8) if to_host else None
+        _check(lib().orbx_extract_batch(self._h, C.c_void_p(d_images_ptr), n_frames, C.c_size_t(frame_stride), width,
+                                        height, stride, channels, _p(kps), capacity, _p(counts), _p(desc)),
+               "orbx_extract_batch")
+        return kps, counts, desc
+
+    def device_results(self):
+        kp, desc, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap = C.c_int()
+        _check(lib().orbx_extractor_device_results(self._h, C.byref(kp), C.byref(desc), C.byref(cnt), C.byref(cap)),
+               "orbx_extractor_device_results")
+        return kp.value, desc.value, cnt.value, cap.value
+
+    def last_timings(self):
+        ms = np.zeros(8, np.float32)
+        n = lib().orbx_extractor_last_timings(self._h, _p(ms), 8)
+        names = ["gray", "resize", "fast", "nms", "emit", "harris", "blur", "brief"]
+        return dict(zip(names[:n], ms[:n].tolist()))
+
+
+class Matcher:
+    """Handle over orbx_matcher (ORBMatcher of the reference)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().orbx_matcher_create(device, C.byref(self._h)), "orbx_matcher_create")
+
+    def close(self):
+        if self._h:
+            lib().orbx_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().orbx_matcher_set_stream(self._h, C.c_void_p(stream_ptr)), "orbx_matcher_set_stream")
+
+    def match_hamming(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        idx = np.zeros(len(q), np.int32)
+        dist = np.zeros(len(q), np.int32)
+        _check(lib().orbx_match_hamming(self._h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)),
+               "orbx_match_hamming")
+        return idx, dist
+
+    def match_hamming_batch(self, d_query, d_n_query, query_stride, d_train, d_n_train, train_stride, n_pairs,
+                            max_query, max_train, d_idx, d_dist, out_stride):
+        _check(lib().orbx_match_hamming_batch(self._h, C.c_void_p(d_query), C.c_void_p(d_n_query),
+                                              C.c_size_t(query_stride), C.c_void_p(d_train), C.c_void_p(d_n_train),
+                                              C.c_size_t(train_stride), n_pairs, max_query, max_train,
+                                              C.c_void_p(d_idx), C.c_void_p(d_dist), C.c_size_t(out_stride)),
+               "orbx_match_hamming_batch")
+
+    def match(self, descriptors, ref_descriptors, filter_matches=True):
+        """ORBMatcher::match(descriptors, ref_descriptors, matches, filter) (orb_matcher.cpp:719-733)."""
+        idx, dist = self.match_hamming(descriptors, ref_descriptors)
+        m = np.zeros(len(idx), MATCH_DTYPE)
+        m["query"] = np.arange(len(idx))
+        m["train"] = idx
+        m["img"] = 0
+        m["distance"] = dist.astype(np.float32)
+        if filter_matches:
+            m = filter_matches_host(m, len(idx))
+        return m
+
+    def match_radius(self, kp, ref_kp, desc, ref_desc, max_pixel_dist):
+        kp = np.ascontiguousarray(kp, KP_DTYPE)
+        ref_kp = np.ascontiguousarray(ref_kp, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+        out = np.zeros(max(len(kp), 1), MATCH_DTYPE)
+        n = C.c_int()
+        _check(lib().orbx_match_radius(self._h, _p(kp), len(kp), _p(ref_kp), len(ref_kp), _p(desc), _p(ref_desc),
+                                       C.c_double(max_pixel_dist), _p(out), C.byref(n)), "orbx_match_radius")
+        return out[:n.value].copy()
+
+    def match_projection_frame(self, g, start, items, kps, desc, ref_kps, ref_has_mp, proj_xy, proj_z, ref_desc,
+                               scale_factors, level_mode, radius, check_orientation):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+        ref_has_mp = np.ascontiguousarray(ref_has_mp, np.uint8)
+        proj_xy = np.ascontiguousarray(proj_xy, np.float32)
+        proj_z = np.ascontiguousarray(proj_z, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        start = np.ascontiguousarray(start, np.int32)
+        items = np.ascontiguousarray(items, np.int32)
+        out = np.zeros(max(len(kps), 1), MATCH_DTYPE)
+        n = C.c_int()
+        _check(lib().orbx_match_projection_frame(self._h, C.byref(g), _p(start), _p(items), _p(kps), len(kps),
+                                                 _p(desc), _p(ref_kps), len(ref_kps), _p(ref_has_mp), _p(proj_xy),
+                                                 _p(proj_z), _p(ref_desc), _p(sf), len(sf), level_mode,
+                                                 C.c_float(radius), int(check_orientation), _p(out), C.byref(n)),
+               "orbx_match_projection_frame")
+        return out[:n.value].copy()
+
+    def match_projection_points(self, g, start, items, kps, desc, in_view, proj_xy, pred_level, view_cos, pt_desc,
+                                scale_factors, radius, nn_ratio):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        in_view = np.ascontiguousarray(in_view, np.uint8)
+        proj_xy = np.ascontiguousarray(proj_xy, np.float32)
+        pred_level = np.ascontiguousarray(pred_level, np.int32)
+        view_cos = np.ascontiguousarray(view_cos, np.float32)
+        pt_desc = np.ascontiguousarray(pt_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        start = np.ascontiguousarray(start, np.int32)
+        items = np.ascontiguousarray(items, np.int32)
+        out = np.zeros(max(len(kps), 1), MATCH_DTYPE)
+        n = C.c_int()
+        _check(lib().orbx_match_projection_points(self._h, C.byref(g), _p(start), _p(items), _p(kps), len(kps),
+                                                  _p(desc), len(in_view), _p(in_view), _p(proj_xy), _p(pred_level),
+                                                  _p(view_cos), _p(pt_desc), _p(sf), len(sf), C.c_float(radius),
+                                                  C.c_float(nn_ratio), _p(out), C.byref(n)),
+               "orbx_match_projection_points")
+        return out[:n.value].copy()
+
+
+def filter_matches_host(matches, n_descriptor_rows):
+    m = np.ascontiguousarray(matches, MATCH_DTYPE).copy()
+    n = C.c_int(len(m))
+    _check(lib().orbx_filter_matches(_p(m), C.byref(n), n_descriptor_rows), "orbx_filter_matches")
+    return m[:n.value].copy()
+
+
+def make_grid(bounds, cols=64, rows=64):
+    """bounds = (min_x, max_x, min_y, max_y); cell sizes as Frame::setupGrid computes them (int = float / int)."""
+    min_x, max_x, min_y, max_y = [np.float32(v) for v in bounds]
+    return Grid(float(min_x), float(min_y), float(max_x), float(max_y), cols, rows, int((max_x - min_x) / cols),
+                int((max_y - min_y) / rows))
+
+
+def assign_grid(g, kps):
+    k = np.ascontiguousarray(kps, KP_DTYPE).copy()
+    ncell = g.grid_cols * g.grid_rows
+    start = np.zeros(ncell + 1, np.int32)
+    items = np.zeros(max(len(k), 1), np.int32)
+    n = C.c_int(len(k))
+    _check(lib().orbx_assign_grid(C.byref(g), _p(k), C.byref(n), _p(start), _p(items)), "orbx_assign_grid")
+    return k[:n.value].copy(), start, items[:n.value].copy()
+
+
+def ransac_make_sets(n, iterations, seed0):
+    out = np.zeros((iterations, 8), np.uint32)
+    _check(lib().orbx_ransac_make_sets(n, iterations, C.c_uint32(seed0), _p(out)), "orbx_ransac_make_sets")
+    return out
+
+
+class Ransac:
+    """Handle over orbx_ransac (Initializer::findFundamentalAndHomography of the reference)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().orbx_ransac_create(device, C.byref(self._h)), "orbx_ransac_create")
+
+    def close(self):
+        if self._h:
+            lib().orbx_ransac_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().orbx_ransac_set_stream(self._h, C.c_void_p(stream_ptr)), "orbx_ransac_set_stream")
+
+    def fh(self, pts, ref, sets8, sigma=1.0):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        ref = np.ascontiguousarray(ref, np.float32).reshape(-1, 2)
+        sets8 = np.ascontiguousarray(sets8, np.uint32).reshape(-1, 8)
+        n = len(pts)
+        F = np.zeros(9, np.float32)
+        H = np.zeros(9, np.float32)
+        inl_f = np.zeros(n, np.uint8)
+        inl_h = np.zeros(n, np.uint8)
+        sf, sh = C.c_double(), C.c_double()
+        best = np.zeros(2, np.int32)
+        _check(lib().orbx_ransac_fh(self._h, _p(pts), _p(ref), n, _p(sets8), len(sets8), C.c_double(sigma), _p(F),
+                                    _p(H), _p(inl_f), _p(inl_h), C.byref(sf), C.byref(sh), _p(best)),
+               "orbx_ransac_fh")
+        return dict(F=F.reshape(3, 3), H=H.reshape(3, 3), inliers_f=inl_f, inliers_h=inl_h, score_f=sf.value,
+                    score_h=sh.value, best_it=best)
+
+    def fh_all(self, pts, ref, sets8, sigma=1.0):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        ref = np.ascontiguousarray(ref, np.float32).reshape(-1, 2)
+        sets8 = np.ascontiguousarray(sets8, np.uint32).reshape(-1, 8)
+        it = len(sets8)
+        F = np.zeros((it, 9), np.float32)
+        H = np.zeros((it, 9), np.float32)
+        Hi = np.zeros((it, 9), np.float32)
+        sf = np.zeros(it, np.float32)
+        sh = np.zeros(it, np.float32)
+        _check(lib().orbx_ransac_fh_all(self._h, _p(pts), _p(ref), len(pts), _p(sets8), it, C.c_double(sigma), _p(F),
+                                        _p(H), _p(Hi), _p(sf), _p(sh)), "orbx_ransac_fh_all")
+        return F, H, Hi, sf, sh
+
+    def fh_batch(self, d_pts, d_ref, n, d_sets, iterations, n_pairs, sigma, d_F, d_H, d_inl_f, d_inl_h, d_scores,
+                 d_best):
+        _check(lib().orbx_ransac_fh_batch(self._h, C.c_void_p(d_pts), C.c_void_p(d_ref), n, C.c_void_p(d_sets),
+                                          iterations, n_pairs, C.c_double(sigma), C.c_void_p(d_F), C.c_void_p(d_H),
+                                          C.c_void_p(d_inl_f), C.c_void_p(d_inl_h), C.c_void_p(d_scores),
+                                          C.c_void_p(d_best)), "orbx_ransac_fh_batch")
+
+    def last_timings(self):
+        ms = np.zeros(5, np.float32)
+        n = lib().orbx_ransac_last_timings(self._h, _p(ms), 5)
+        names = ["normalize", "solve", "score_f", "score_h", "select"]
+        return dict(zip(names[:n], ms[:n].tolist()))

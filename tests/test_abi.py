@@ -1,0 +1,79 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/orbx.h declares; the
+host-only entry points (no GPU work) agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from orb_slam_amd import orbx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    declared = set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = orbx.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(orbx.SYMBOLS)
+
+
+def test_status_strings():
+    lib = orbx.lib()
+    assert lib.orbx_status_string(0) == b"ok"
+    assert lib.orbx_status_string(2) == b"capacity exceeded"
+
+
+def test_struct_layouts_match_opencv():
+    assert orbx.KP_DTYPE.itemsize == 28 and orbx.MATCH_DTYPE.itemsize == 16
+    assert C.sizeof(orbx.ExtractorParams) == 32 and C.sizeof(orbx.Grid) == 32
+
+
+def test_bad_arguments_do_not_touch_the_gpu():
+    lib = orbx.lib()
+    assert lib.orbx_extractor_create(None, 640, 480, 1, 0, None) == orbx.BAD_ARG
+    p = orbx.make_params(wta_k=3)
+    h = C.c_void_p()
+    assert lib.orbx_extractor_create(C.byref(p), 640, 480, 1, 0, C.byref(h)) == orbx.UNSUPPORTED
+    n = C.c_int(-1)
+    assert lib.orbx_filter_matches(None, C.byref(n), 0) == orbx.BAD_ARG
+    assert lib.orbx_ransac_make_sets(4, 10, 1, None) == orbx.BAD_ARG
+
+
+def test_filter_matches_matches_oracle(oracle):
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 50, 1000):
+        m = np.zeros(n, orbx.MATCH_DTYPE)
+        m["query"] = np.arange(n)
+        m["train"] = rng.integers(0, max(2, n // 3), n)
+        m["distance"] = rng.integers(0, 90, n).astype(np.float32)
+        a = orbx.filter_matches_host(m, n)
+        b = oracle.filter_matches(m, n)
+        assert np.array_equal(a, b.astype(orbx.MATCH_DTYPE))
+    assert len(orbx.filter_matches_host(np.zeros(0, orbx.MATCH_DTYPE), 0)) == 0
+
+
+def test_assign_grid_matches_oracle(oracle):
+    rng = np.random.default_rng(6)
+    k = np.zeros(3000, orbx.KP_DTYPE)
+    k["x"] = rng.uniform(-5, 645, len(k)).astype(np.float32)
+    k["y"] = rng.uniform(-5, 485, len(k)).astype(np.float32)
+    k["octave"] = rng.integers(0, 8, len(k))
+    for bounds in ((0, 640, 0, 480), (10.803785, 626.0599, 14.68408, 473.3248)):
+        g = orbx.make_grid(bounds)
+        og = oracle.grid_params(bounds)
+        assert (g.grid_size_x, g.grid_size_y) == (og.grid_size_x, og.grid_size_y)
+        ka, sa, ia = orbx.assign_grid(g, k)
+        kb, sb, ib = oracle.assign_grid(og, k)
+        assert np.array_equal(ka, kb) and np.array_equal(sa, sb) and np.array_equal(ia, ib)
+
+
+def test_ransac_sets_match_oracle(oracle):
+    for n, it, seed in ((8, 5, 1), (100, 50, 7), (2000, 200, 3)):
+        assert np.array_equal(orbx.ransac_make_sets(n, it, seed), oracle.ransac_sets(n, it, seed))
+    s = orbx.ransac_make_sets(50, 20, 2)
+    assert all(len(set(r.tolist())) == 8 for r in s)

@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
+Integer / byte / index results must be bit-exact; floating-point results here are bit-exact as well because the
+kernels evaluate the reference's arithmetic in the reference's order (tolerance 0 unless a test says otherwise)."""
+import numpy as np
+import pytest
+
+from orb_slam_amd import orbx
+from tests.conftest import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ex8000():
+    e = orbx.Extractor(n_key_points=8000, level_pyramid=8, max_width=1024, max_height=768, max_batch=8)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def ex1000():
+    e = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=1024, max_height=768, max_batch=8)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    m = orbx.Matcher()
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def ransac():
+    r = orbx.Ransac()
+    yield r
+    r.close()
+
+
+def _cases(test_images):
+    return [("img1", test_images[0]), ("img2", test_images[1]), ("gray1", test_images[0][:, :, 1].copy()),
+            ("synth_odd", synth_image(11, 333, 257)), ("synth_color", synth_image(12, 401, 299, 3)),
+            ("small", synth_image(13, 150, 120))]
+
+
+def test_layout_matches_oracle(oracle, ex8000):
+    p = oracle.orb_params(nfeatures=8000)
+    for (w, h) in ((640, 480), (333, 257), (1024, 768), (150, 120)):
+        aw, ah, rects, scales = ex8000.layout(w, h)
+        oaw, oah, orects, oscales = oracle.layout(p, w, h)
+        assert (aw, ah) == (oaw, oah) and np.array_equal(rects, orects) and np.array_equal(scales, oscales)
+
+
+def test_pyramid_fast_blur_planes_bit_exact(oracle, ex8000, test_images):
+    p = oracle.orb_params(nfeatures=8000)
+    for name, img in _cases(test_images):
+        h, w = img.shape[:2]
+        k = ex8000.detect(img)
+        ok_, desc = ex8000.compute(img, k)
+        atlas = ex8000.read_plane(0, w, h)
+        score = ex8000.read_plane(1, w, h)
+        blur = ex8000.read_plane(2, w, h)
+        oatlas, rects, _ = oracle.pyramid(p, img)
+        oblur = oracle.blur(p, oatlas, w, h)
+        for l, (rx, ry, rw, rh) in enumerate(rects):
+            b = 32
+            assert np.array_equal(atlas[ry - b:ry + rh + b, rx - b:rx + rw + b],
+                                  oatlas[ry - b:ry + rh + b, rx - b:rx + rw + b]), (name, "pyramid", l)
+            lvl = np.ascontiguousarray(oatlas[ry:ry + rh, rx:rx + rw])
+            assert np.array_equal(score[ry:ry + rh, rx:rx + rw], oracle.fast_scores(lvl, 20)), (name, "fast", l)
+            assert np.array_equal(blur[ry:ry + rh, rx:rx + rw], oblur[ry:ry + rh, rx:rx + rw]), (name, "blur", l)
+
+
+@pytest.mark.parametrize("nkp", [8000, 1000])
+def test_detect_and_compute_bit_exact(oracle, ex8000, ex1000, test_images, nkp):
+    ex = ex8000 if nkp == 8000 else ex1000
+    p = oracle.orb_params(nfeatures=nkp)
+    for name, img in _cases(test_images):
+        k = ex.detect(img)
+        ok_ = oracle.detect(p, img)
+        assert len(k) == len(ok_), (name, len(k), len(ok_))
+        assert np.array_equal(k, ok_.astype(orbx.KP_DTYPE)), name
+        k2, d = ex.compute(img, k)
+        ok2, od = oracle.compute(p, img, ok_)
+        assert np.array_equal(k2, ok2.astype(orbx.KP_DTYPE)) and np.array_equal(d, od), name
+    if nkp == 8000:  # the reference's own known answers, through the HIP path
+        assert len(ex.detect(test_images[0])) == 4583 and len(ex.detect(test_images[1])) == 4652
+
+
+def test_compute_on_moved_unsorted_keypoints(oracle, ex1000, test_images):
+    # compute() after undistortion: float coordinates, some pushed over the border, octaves shuffled
+    p = oracle.orb_params(nfeatures=1000)
+    rng = np.random.default_rng(4)
+    img = test_images[0]
+    k = oracle.detect(p, img)
+    k["x"] += rng.uniform(-6, 6, len(k)).astype(np.float32)
+    k["y"] += rng.uniform(-6, 6, len(k)).astype(np.float32)
+    k[:5]["x"] = np.float32(30.5)
+    k[5:9]["y"] = np.float32(449.5)
+    for perm in (np.arange(len(k)), rng.permutation(len(k))):
+        kk = k[perm]
+        a_k, a_d = ex1000.compute(img, kk)
+        o_k, o_d = oracle.compute(p, img, kk)
+        assert len(a_k) == len(o_k) < len(kk)
+        assert np.array_equal(a_k, o_k.astype(orbx.KP_DTYPE)) and np.array_equal(a_d, o_d)
+    e_k, e_d = ex1000.compute(img, k[:0])
+    assert len(e_k) == 0
+
+
+def test_detect_edge_cases(oracle, ex1000):
+    p = oracle.orb_params(nfeatures=1000)
+    flat = np.full((120, 160), 77, np.uint8)
+    assert len(ex1000.detect(flat)) == 0 == len(oracle.detect(p, flat))
+    tiny = synth_image(3, 70, 66)  # upper levels are smaller than twice the border: they yield nothing
+    assert np.array_equal(ex1000.detect(tiny), oracle.detect(p, tiny).astype(orbx.KP_DTYPE))
+    with pytest.raises(orbx.OrbxError) as e:
+        ex1000.detect(np.zeros((2000, 2000), np.uint8))
+    assert e.value.status == orbx.CAPACITY
+    img = synth_image(5, 320, 240)
+    with pytest.raises(orbx.OrbxError) as e:
+        ex1000.detect(img, capacity=10)
+    assert e.value.status == orbx.CAPACITY
+
+
+def test_extract_batch_equals_per_frame(oracle, test_images):
+    import torch
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=6)
+    p = oracle.orb_params(nfeatures=1000)
+    frames = [test_images[0], test_images[1]] + [synth_image(20 + i, 640, 480, 3) for i in range(4)]
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    cap = 1500
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    for f, img in enumerate(frames):
+        ok_ = oracle.detect(p, img)
+        ok2, od = oracle.compute(p, img, ok_)
+        assert counts[f] == len(ok2)
+        assert np.array_equal(kps[f, :counts[f]], ok2.astype(orbx.KP_DTYPE))
+        assert np.array_equal(desc[f, :counts[f]], od)
+    ex.close()
+
+
+def test_match_hamming_bit_exact(oracle, matcher, ex1000, test_images):
+    rng = np.random.default_rng(7)
+    cases = []
+    for nq, nt in ((1, 1), (5, 300), (1000, 1000), (257, 4099), (2000, 77)):
+        cases.append((rng.integers(0, 256, (nq, 32), dtype=np.uint8), rng.integers(0, 256, (nt, 32), dtype=np.uint8)))
+    # ties: duplicated train rows and few distinct values -> the lowest train index must win
+    t = rng.integers(0, 2, (600, 32), dtype=np.uint8) * 255
+    cases.append((t[rng.integers(0, 600, 900)].copy(), np.concatenate([t, t])))
+    r = [ex1000.compute(img, ex1000.detect(img)) for img in test_images]
+    cases.append((r[0][1], r[1][1]))
+    for q, tr in cases:
+        idx, dist = matcher.match_hamming(q, tr)
+        oidx, odist = oracle.match_hamming(q, tr)
+        assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    idx, dist = matcher.match_hamming(cases[2][0], np.zeros((0, 32), np.uint8))
+    assert np.all(idx == -1) and np.all(dist == -1)
+    # ORBMatcher::match(..., filter=true) end to end
+    m = matcher.match(r[0][1], r[1][1], True)
+    om = oracle.filter_matches(oracle.matches_from(*oracle.match_hamming(r[0][1], r[1][1])))
+    assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE))
+    assert len(set(m["train"][1:].tolist())) == len(m) - 1
+
+
+def test_match_radius_bit_exact(oracle, matcher, ex8000, test_images):
+    r = [ex8000.compute(img, ex8000.detect(img)) for img in test_images]
+    for radius in (100.0, 12.5, 0.0):
+        m = matcher.match_radius(r[0][0], r[1][0], r[0][1], r[1][1], radius)
+        om = oracle.match_radius(r[0][0], r[1][0], r[0][1], r[1][1], radius)
+        assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE)), radius
+    m = matcher.match_radius(r[0][0], r[1][0], r[0][1], r[1][1], 100.0)
+    assert len(m) >= 4500  # src/tests/geometry/orb_matcher_tests.cpp:39
+
+
+def _projection_case(oracle, ex, img_a, img_b, rng, bounds):
+    p = oracle.orb_params(nfeatures=1000)
+    ka, da = ex.compute(img_a, ex.detect(img_a))
+    kb, db = ex.compute(img_b, ex.detect(img_b))
+    g = orbx.make_grid(bounds)
+    ka, start, items = orbx.assign_grid(g, ka)
+    da = da[:len(ka)] if len(da) == len(ka) else None
+    return g, ka, start, items, kb, db
+
+
+def test_projection_matchers_bit_exact(oracle, matcher, ex1000, test_images):
+    rng = np.random.default_rng(9)
+    bounds = (10.803785, 626.0599, 14.68408, 473.3248)
+    g = orbx.make_grid(bounds)
+    og = oracle.grid_params(bounds)
+    det = [ex1000.detect(img) for img in test_images]
+    k0, start, items = orbx.assign_grid(g, det[0])
+    k0, d0 = ex1000.compute(test_images[0], k0)
+    kr, dr = ex1000.compute(test_images[1], det[1])
+    _, sf, _, _, _ = ex1000.scale_tables()
+    n_ref = len(kr)
+    proj = np.stack([kr["x"], kr["y"]], 1) + rng.normal(0, 4, (n_ref, 2)).astype(np.float32)
+    proj[:7] = [[-3, 5], [700, 100], [320, -2], [320, 500], [11, 15], [626, 473], [5000, 5000]]
+    z = np.ones(n_ref, np.float32)
+    z[rng.integers(0, n_ref, 20)] = -1
+    has = (rng.uniform(size=n_ref) > 0.1).astype(np.uint8)
+    has[0] = 1
+    for level_mode in (0, 1, 2):
+        for radius, orient in ((15.0, True), (30.0, False), (7.0, True)):
+            m = matcher.match_projection_frame(g, start, items, k0, d0, kr, has, proj, z, dr, sf, level_mode,
+                                               radius, orient)
+            om = oracle.match_projection_frame(og, start, items, k0, d0, kr, has, proj, z, dr, sf, level_mode,
+                                               radius, orient)
+            assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE)), (level_mode, radius, orient)
+            if level_mode == 0 and radius == 15.0:
+                assert len(m) > 50
+    # map-point variant
+    in_view = has.copy()
+    pred = np.clip(kr["octave"] + rng.integers(-1, 2, n_ref), 0, 7).astype(np.int32)
+    vcos = rng.uniform(0.99, 1.0, n_ref).astype(np.float32)
+    for radius, ratio in ((1.0, 0.6), (3.0, 0.8), (5.0, 0.95)):
+        m = matcher.match_projection_points(g, start, items, k0, d0, in_view, proj, pred, vcos, dr, sf, radius, ratio)
+        om = oracle.match_projection_points(og, start, items, k0, d0, in_view, proj, pred, vcos, dr, sf, radius, ratio)
+        assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE)), (radius, ratio)
+    assert len(m) > 20
+
+
+def _two_view(rng, n, outliers, noise=0.5, planar=False):
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n),
+                  np.full(n, 4.0) if planar else rng.uniform(2, 6, n)], 1)
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    a = 0.05
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([0.3, 0.02, 0.05])
+    x1 = (K @ X.T).T
+    x2 = (K @ (R @ X.T + t[:, None])).T
+    ref = x1[:, :2] / x1[:, 2:]
+    pts = x2[:, :2] / x2[:, 2:] + rng.normal(0, noise, (n, 2))
+    idx = rng.choice(n, outliers, replace=False)
+    pts[idx] = np.stack([rng.uniform(0, 640, outliers), rng.uniform(0, 480, outliers)], 1)
+    return pts.astype(np.float32), ref.astype(np.float32)
+
+
+def test_ransac_per_hypothesis_bit_exact(oracle, ransac, utils_points):
+    rng = np.random.default_rng(21)
+    cases = [_two_view(rng, 300, 90), _two_view(rng, 2000, 600), _two_view(rng, 150, 30, planar=True),
+             (utils_points["points"], utils_points["ref_points"]), _two_view(rng, 8, 0), _two_view(rng, 2500, 500)]
+    for ci, (pts, ref) in enumerate(cases):
+        it = 200 if len(pts) > 8 else 3
+        sets = orbx.ransac_make_sets(len(pts), it, 100 + ci)
+        F, H, Hi, sf, sh = ransac.fh_all(pts, ref, sets, 1.0)
+        oF, oH, oHi, osf, osh = oracle.ransac_fh_all(pts, ref, sets, 1.0)
+        for name, a, b in (("F", F, oF), ("H", H, oH), ("Hinv", Hi, oHi), ("score_f", sf, osf), ("score_h", sh, osh)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (ci, name, np.abs(a - b).max())
+
+
+def test_ransac_result_identical(oracle, ransac, utils_points):
+    rng = np.random.default_rng(22)
+    cases = [_two_view(rng, 500, 150), _two_view(rng, 1200, 300, planar=True),
+             (utils_points["points"], utils_points["ref_points"])]
+    for ci, (pts, ref) in enumerate(cases):
+        for sigma in (1.0, 2.0):
+            sets = orbx.ransac_make_sets(len(pts), 500, 7 + ci)
+            r = ransac.fh(pts, ref, sets, sigma)
+            o = oracle.ransac_fh(pts, ref, sets, sigma)
+            assert np.array_equal(r["best_it"], o["best_it"])
+            assert np.array_equal(r["F"], o["F"]) and np.array_equal(r["H"], o["H"])
+            assert np.array_equal(r["inliers_f"], o["inliers_f"]) and np.array_equal(r["inliers_h"], o["inliers_h"])
+            assert r["score_f"] == o["score_f"] and r["score_h"] == o["score_h"]  # well inside the 1e-5 budget
+            assert r["inliers_f"].sum() > 0.5 * len(pts) or ci == 1
+    # degenerate input: every hypothesis scores 0 -> no winner, matrices untouched
+    pts = np.zeros((20, 2), np.float32)
+    ref = np.zeros((20, 2), np.float32)
+    sets = orbx.ransac_make_sets(20, 10, 1)
+    r = ransac.fh(pts, ref, sets, 1.0)
+    o = oracle.ransac_fh(pts, ref, sets, 1.0)
+    assert np.array_equal(r["best_it"], o["best_it"])
+    with pytest.raises(orbx.OrbxError):
+        ransac.fh(pts[:5], ref[:5], sets, 1.0)
+    bad = sets.copy()
+    bad[0, 0] = 999
+    with pytest.raises(orbx.OrbxError):
+        ransac.fh(pts, ref, bad, 1.0)
+
+
+def test_ransac_batch_equals_single(oracle, ransac):
+    import torch
+    rng = np.random.default_rng(23)
+    P, n, it = 5, 700, 200
+    data = [_two_view(rng, n, 200) for _ in range(P)]
+    pts = np.stack([d[0] for d in data])
+    ref = np.stack([d[1] for d in data])
+    sets = np.stack([orbx.ransac_make_sets(n, it, 50 + i) for i in range(P)])
+    d_pts, d_ref = torch.from_numpy(pts).cuda(), torch.from_numpy(ref).cuda()
+    d_sets = torch.from_numpy(sets.astype(np.int64)).to(torch.int32).cuda()
+    d_F = torch.zeros((P, 9), dtype=torch.float32, device="cuda")
+    d_H = torch.zeros_like(d_F)
+    d_if = torch.zeros((P, n), dtype=torch.uint8, device="cuda")
+    d_ih = torch.zeros_like(d_if)
+    d_sc = torch.zeros((P, 2), dtype=torch.float32, device="cuda")
+    d_best = torch.zeros((P, 2), dtype=torch.int32, device="cuda")
+    ransac.fh_batch(d_pts.data_ptr(), d_ref.data_ptr(), n, d_sets.data_ptr(), it, P, 1.0, d_F.data_ptr(),
+                    d_H.data_ptr(), d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_best.data_ptr())
+    torch.cuda.synchronize()
+    for p in range(P):
+        o = oracle.ransac_fh(pts[p], ref[p], sets[p], 1.0)
+        assert np.array_equal(d_best[p].cpu().numpy(), o["best_it"])
+        assert np.array_equal(d_F[p].cpu().numpy().reshape(3, 3), o["F"])
+        assert np.array_equal(d_H[p].cpu().numpy().reshape(3, 3), o["H"])
+        assert np.array_equal(d_if[p].cpu().numpy(), o["inliers_f"])
+        assert np.array_equal(d_ih[p].cpu().numpy(), o["inliers_h"])
+        assert d_sc[p, 0].item() == o["score_f"] and d_sc[p, 1].item() == o["score_h"]
