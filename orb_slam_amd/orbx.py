@@ -52,6 +52,36 @@ class OrbxError(RuntimeError):
 
 
 _lib = None
+_hip = None
+
+
+def _load_hip_runtime():
+    """liborbx.so carries no DT_NEEDED on the HIP runtime: exactly one libamdhip64 may live in a process, and when
+    PyTorch is installed it must be the one PyTorch bundles (torch loads that file by RPATH).  Load it globally
+    before liborbx so its HIP symbols resolve against it."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    candidates = []
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            candidates.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    err = None
+    for c in candidates:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            _hip = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return _hip
+        except OSError as e:
+            err = e
+    raise ImportError(f"no HIP runtime (libamdhip64.so) could be loaded: {err}")
 
 
 def lib():
@@ -60,6 +90,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_slam_amd/csrc` "
                               "(python -c 'import __graft_entry__ as g; g.build()')")
+        _load_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _lib.orbx_status_string.restype = C.c_char_p
         _lib.orbx_last_error.restype = C.c_char_p

@@ -129,6 +129,7 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     p = oracle.orb_params(nfeatures=1000)
     frames = [test_images[0], test_images[1]] + [synth_image(20 + i, 640, 480, 3) for i in range(4)]
     dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
     cap = 1500
     kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
     for f, img in enumerate(frames):
@@ -233,7 +234,7 @@ def _two_view(rng, n, outliers, noise=0.5, planar=False):
     pts = x2[:, :2] / x2[:, 2:] + rng.normal(0, noise, (n, 2))
     idx = rng.choice(n, outliers, replace=False)
     pts[idx] = np.stack([rng.uniform(0, 640, outliers), rng.uniform(0, 480, outliers)], 1)
-    return pts.astype(np.float32), ref.astype(np.float32)
+    return np.ascontiguousarray(pts, np.float32), np.ascontiguousarray(ref, np.float32)
 
 
 def test_ransac_per_hypothesis_bit_exact(oracle, ransac, utils_points):
@@ -283,8 +284,8 @@ def test_ransac_batch_equals_single(oracle, ransac):
     rng = np.random.default_rng(23)
     P, n, it = 5, 700, 200
     data = [_two_view(rng, n, 200) for _ in range(P)]
-    pts = np.stack([d[0] for d in data])
-    ref = np.stack([d[1] for d in data])
+    pts = np.ascontiguousarray(np.stack([d[0] for d in data]))
+    ref = np.ascontiguousarray(np.stack([d[1] for d in data]))
     sets = np.stack([orbx.ransac_make_sets(n, it, 50 + i) for i in range(P)])
     d_pts, d_ref = torch.from_numpy(pts).cuda(), torch.from_numpy(ref).cuda()
     d_sets = torch.from_numpy(sets.astype(np.int64)).to(torch.int32).cuda()
@@ -294,6 +295,7 @@ def test_ransac_batch_equals_single(oracle, ransac):
     d_ih = torch.zeros_like(d_if)
     d_sc = torch.zeros((P, 2), dtype=torch.float32, device="cuda")
     d_best = torch.zeros((P, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # the handle launches on its own stream: inputs must have landed
     ransac.fh_batch(d_pts.data_ptr(), d_ref.data_ptr(), n, d_sets.data_ptr(), it, P, 1.0, d_F.data_ptr(),
                     d_H.data_ptr(), d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_best.data_ptr())
     torch.cuda.synchronize()
