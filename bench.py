@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Throughput of the ORB front-end hot path on MI355X.
+
+One step = one pass of the hot path over one batch of synthetic VGA frames resident in HBM:
+per frame ORB extract (detect -> undistort -> bucket grid -> compute, the sequence of
+MonoFrame::extractFeatures) at 1000 keypoints / 8 levels x 1.2, then the windowed (projection)
+match of every frame against its predecessor.  Frames are sharded over ranks with no collective on
+the data path (weak scaling).  Prints ONE JSON line on rank 0.
+
+The CPU oracle is used only for the `cpu_baseline` leg (a reported number, never the thing measured).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 640, 480
+NKP, NLEVELS, CAP = 1000, 8, 1280
+# cfg/camera.yaml `camera:` block of the reference (TUM freiburg1), distortion active
+CAM = dict(fx=517.3, fy=516.5, cx=318.6, cy=255.3, dist=[0.2624, -0.9531, -0.0054, 0.0026, 1.1633])
+RADIUS = 15.0  # Tracker::trackWithMotionModel, monocular (src/tracker.cpp:304-308)
+
+
+class DevView:
+    """Wraps a raw device pointer for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def make_sequence(torch, base_bgr, n_frames, first_index, device):
+    """Smooth random homography walk over the reference test image + Gaussian noise, rendered on the GPU.
+    Returns uint8 [n, H, W, 3] frames and the 3x3 maps H_f with x_f = H_f x_base (float64, host)."""
+    rng = np.random.default_rng(2)
+    total = first_index + n_frames
+    Hs = []
+    a = np.zeros(8)
+    for f in range(total):
+        a = 0.98 * a + rng.normal(0, 1, 8) * np.array([2e-4, 2e-4, 0.15, 2e-4, 2e-4, 0.15, 2e-7, 2e-7])
+        Hm = np.array([[1 + a[0], a[1], a[2] * 4], [a[3], 1 + a[4], a[5] * 4], [a[6], a[7], 1.0]])
+        Hs.append(Hm)
+    Hs = np.stack(Hs[first_index:])
+    base = torch.from_numpy(base_bgr.astype(np.float32)).to(device).permute(2, 0, 1)[None]
+    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    ones = torch.ones_like(xs)
+    pix = torch.stack([xs, ys, ones], 0).reshape(3, -1)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + first_index)
+    out = torch.empty((n_frames, H, W, 3), dtype=torch.uint8, device=device)
+    for f in range(n_frames):
+        Hinv = torch.from_numpy(np.linalg.inv(Hs[f]).astype(np.float32)).to(device)
+        src = Hinv @ pix
+        sx = src[0] / src[2]
+        sy = src[1] / src[2]
+        grid = torch.stack([sx / (W - 1) * 2 - 1, sy / (H - 1) * 2 - 1], -1).reshape(1, H, W, 2)
+        img = torch.nn.functional.grid_sample(base, grid, mode="bilinear", padding_mode="reflection",
+                                              align_corners=True)
+        img = img + torch.randn(img.shape, generator=gen, device=device) * 2.0
+        out[f] = img.clamp(0, 255).round().to(torch.uint8)[0].permute(1, 2, 0)
+    return out.contiguous(), Hs
+
+
+def algorithmic_bytes(n_kp):
+    """Per-frame algorithmic HBM bytes of the extraction stages (VGA colour, 8 levels x 1.2)."""
+    lv = [(int(round(W / 1.2 ** l)), int(round(H / 1.2 ** l))) for l in range(NLEVELS)]
+    P = sum(w * h for w, h in lv)
+    per_kernel = {
+        "gray": 3 * W * H + W * H,                      # read BGR, write level 0
+        "resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, NLEVELS)),
+        "fast": 2 * P,                                  # read pyramid, write score map
+        "nms": P + P // 8,                              # read score map, write 1 bit / pixel
+        "emit": P // 8,                                 # read mask
+        "harris": 2 * n_kp * (81 + 709),                # 9x9 + radius-15 disc per surviving candidate (~2x quota)
+        "blur": 2 * P,                                  # read pyramid, write blurred pyramid
+        "brief": n_kp * (512 + 32),                     # 512 samples + 32 descriptor bytes per keypoint
+    }
+    frame_total = 3 * W * H + 4 * P + n_kp * (2 * 81 + 709 + 512)
+    return per_kernel, frame_total
+
+
+def cpu_baseline(frames_bgr, homs, grid_bounds, seconds=12.0):
+    """CPU oracle (scalar C++ port of the reference path) on a bounded sample of the same workload, 1 thread."""
+    from oracle import pyoracle as O
+    p = O.orb_params(nfeatures=NKP, nlevels=NLEVELS)
+    cam = O.camera(CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"], CAM["dist"], W, H)
+    g = O.grid_params(grid_bounds)
+    _, sf, _, _, _ = O.scale_tables(1.2, NLEVELS)
+    prev = None
+    n = 0
+    t0 = time.perf_counter()
+    for f in range(len(frames_bgr)):
+        k = O.detect(p, frames_bgr[f])
+        xy = O.undistort_points(cam, np.stack([k["x"], k["y"]], 1))
+        k["x"], k["y"] = xy[:, 0], xy[:, 1]
+        k, start, items = O.assign_grid(g, k)
+        k, d = O.compute(p, frames_bgr[f], k)
+        if prev is not None:
+            pk, pd, pH = prev
+            q = (homs[f] @ np.linalg.inv(pH) @ np.c_[pk["x"], pk["y"], np.ones(len(pk))].T).T
+            proj = (q[:, :2] / q[:, 2:]).astype(np.float32)
+            O.match_projection_frame(g, start, items, k, d, pk, np.ones(len(pk), np.uint8), proj,
+                                     np.ones(len(pk), np.float32), pd, sf, 0, RADIUS, True)
+        prev = (k, d, homs[f])
+        n += 1
+        if time.perf_counter() - t0 > seconds and n >= 4:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames of the same synthetic VGA sequence, detect+undistort+grid+compute+windowed match, "
+                      f"CPU oracle -O2 single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ransac-pairs", type=int, default=1024)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from orb_slam_amd import orbx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    B = args.frames
+    base = np.load(os.path.join(ROOT, "tests", "golden", "test_images.npz"))["bgr1"]
+    frames, homs = make_sequence(torch, base, B, rank * B, device)
+    torch.cuda.synchronize()
+
+    cam = orbx.make_camera(CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"], CAM["dist"])
+    # Camera::computeImageBounds (camera.cpp:129-162): undistorted corners, clipped to the image
+    corners = orbx.undistort_points(cam, np.array([[0, 0], [W, 0], [0, H], [W, H]], np.float32))
+    bounds = (max(min(corners[0, 0], corners[2, 0]), 0.0), min(max(corners[1, 0], corners[3, 0]), float(W)),
+              max(min(corners[0, 1], corners[1, 1]), 0.0), min(max(corners[2, 1], corners[3, 1]), float(H)))
+    grid = orbx.make_grid(bounds)
+
+    ex = orbx.Extractor(n_key_points=NKP, level_pyramid=NLEVELS, max_width=W, max_height=H, max_batch=B,
+                        device=local_rank)
+    ex.set_frame_model(cam, grid)
+    ex.set_stream(stream)
+    mt = orbx.Matcher(device=local_rank)
+    mt.set_stream(stream)
+    _, sf, _, _, _ = ex.scale_tables()
+
+    n_pairs = B - 1
+    frame_idx = torch.arange(1, B, dtype=torch.int32, device=device)
+    ref_idx = torch.arange(0, B - 1, dtype=torch.int32, device=device)
+    # x_f = H_f H_{f-1}^-1 x_{f-1}: the known inter-frame map stands in for pose + depth of the map points
+    rel = torch.from_numpy(np.stack([homs[f] @ np.linalg.inv(homs[f - 1]) for f in range(1, B)])
+                           .astype(np.float32)).to(device)
+    d_matched = torch.empty((n_pairs, CAP), dtype=torch.int32, device=device)
+    d_dist = torch.empty((n_pairs, CAP), dtype=torch.int32, device=device)
+    d_nm = torch.zeros(n_pairs, dtype=torch.int32, device=device)
+    ncell = grid.grid_cols * grid.grid_rows
+
+    stage_ms = {}
+    match_ms = []
+
+    def step(record=False):
+        ex.extract_batch(frames.data_ptr(), B, W * H * 3, W, H, W * 3, 3, CAP, to_host=False)
+        if record:
+            for k, v in ex.last_timings().items():
+                stage_ms.setdefault(k, []).append(v)
+        kp_ptr, desc_ptr, cnt_ptr, cap = ex.device_results()
+        cs_ptr, ci_ptr = ex.device_grid()
+        kp = torch.as_tensor(DevView(kp_ptr, (B, cap, 7), "<f4"), device=device)
+        xy1 = torch.cat([kp[:-1, :, 0:2], torch.ones((B - 1, cap, 1), device=device)], 2)
+        q = torch.bmm(xy1, rel.transpose(1, 2))
+        proj = (q[:, :, :2] / q[:, :, 2:]).contiguous()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        mt.match_projection_frame_batch(grid, n_pairs, frame_idx.data_ptr(), ref_idx.data_ptr(), kp_ptr, desc_ptr,
+                                        cnt_ptr, cap, cs_ptr, ci_ptr, 0, proj.data_ptr(), 0, sf, 0, RADIUS, True,
+                                        d_matched.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr())
+        e1.record()
+        if record:
+            match_ms.append((e0, e1))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    mean_matches = float(d_nm.float().mean().item())
+    mean_kp = float(torch.as_tensor(DevView(ex.device_results()[2], (B,), "<i4"), device=device).float().mean().item())
+    total_frames = world * B * args.steps
+    value = total_frames / dt
+
+    per_kernel, frame_bytes = algorithmic_bytes(NKP)
+    stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+    stage_avg["match_window"] = float(np.mean([a.elapsed_time(b) for a, b in match_ms]))
+    dom = max((k for k in stage_avg if k in per_kernel), key=lambda k: stage_avg[k])
+    achieved = per_kernel[dom] * B / (stage_avg[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": None,
+                "stage_ms_per_batch": stage_avg, "algorithmic_bytes_per_frame": frame_bytes,
+                "device_ms_per_batch": float(sum(stage_avg.values()))}
+
+    # RANSAC hypotheses/s (second half of the headline metric): 200 iterations x 2000 correspondences per pair
+    ransac = None
+    if args.ransac_pairs > 0:
+        P, n, it = args.ransac_pairs, 2000, 200
+        rng = np.random.default_rng(3 + rank)
+        ref = np.stack([rng.uniform(0, W, (P, n)), rng.uniform(0, H, (P, n))], 2).astype(np.float32)
+        Hm = np.array([[1.01, 0.01, 3.0], [-0.01, 0.99, -2.0], [1e-5, -1e-5, 1.0]])
+        q = ref.astype(np.float64) @ Hm[:2, :2].T + Hm[:2, 2]
+        w = ref.astype(np.float64) @ Hm[2, :2] + 1.0
+        pts = (q / w[..., None] + rng.normal(0, 1.0, (P, n, 2))).astype(np.float32)
+        out = rng.uniform(size=(P, n)) < 0.3
+        pts[out] = np.stack([rng.uniform(0, W, out.sum()), rng.uniform(0, H, out.sum())], 1).astype(np.float32)
+        sets = np.stack([np.stack([rng.choice(n, 8, replace=False) for _ in range(it)]) for _ in range(min(P, 64))])
+        sets = np.tile(sets, (P // len(sets) + 1, 1, 1))[:P].astype(np.int32)
+        d_pts = torch.from_numpy(np.ascontiguousarray(pts)).to(device)
+        d_ref = torch.from_numpy(np.ascontiguousarray(ref)).to(device)
+        d_sets = torch.from_numpy(np.ascontiguousarray(sets)).to(device)
+        d_F = torch.empty((P, 9), dtype=torch.float32, device=device)
+        d_H = torch.empty((P, 9), dtype=torch.float32, device=device)
+        d_if = torch.empty((P, n), dtype=torch.uint8, device=device)
+        d_ih = torch.empty((P, n), dtype=torch.uint8, device=device)
+        d_sc = torch.empty((P, 2), dtype=torch.float32, device=device)
+        d_b = torch.empty((P, 2), dtype=torch.int32, device=device)
+        rs = orbx.Ransac(device=local_rank)
+        rs.set_stream(stream)
+
+        def rstep():
+            rs.fh_batch(d_pts.data_ptr(), d_ref.data_ptr(), n, d_sets.data_ptr(), it, P, 1.0, d_F.data_ptr(),
+                        d_H.data_ptr(), d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_b.data_ptr())
+        rstep()
+        barrier()
+        r0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            rstep()
+        barrier()
+        rdt = time.perf_counter() - r0
+        if world > 1:
+            t = torch.tensor([rdt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt = float(t.item())
+        ransac = {"hypotheses_per_s": world * P * it * 2 * reps / rdt, "pairs": P, "iterations": it,
+                  "correspondences": n, "stage_ms": rs.last_timings(),
+                  "mean_inliers_h": float(d_ih.float().sum(1).mean().item())}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nb = min(B, 64)
+        cpu = cpu_baseline(frames[:nb].cpu().numpy(), homs[:nb], bounds)
+
+    if rank == 0:
+        line = {
+            "metric": "frames/s ORB extract+match @640x480/1k kp; RANSAC hyp/s; 1-8 GPU scaling",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "TUM-fr1-like monocular 640x480 BGR sequence (homography walk of the reference "
+                                   "test image + noise), 1000 kp, 8 levels x1.2: per-frame extract (detect, "
+                                   "undistort, 64x64 grid, compute) + windowed match (radius 15) to the previous frame",
+                       "frames_per_gpu_per_step": B, "mean_keypoints": mean_kp, "mean_window_matches": mean_matches,
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "roofline": roofline, "ransac": ransac, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,6 +90,29 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
                                int width, int height, int stride, int channels,
                                orbx_keypoint* keypoints, int capacity, int32_t* counts, uint8_t* descriptors);
 
+/* Camera model of Camera::undistortPoints (src/geometry/camera.cpp:97-126 -> cv::undistortPoints with P = K).
+   Intrinsics and distortion as the reference holds them (cv::Mat_<float> widened to double). */
+typedef struct { double fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_camera;
+
+/* Frame bucket grid (Frame::setupGrid / assignFeaturesToGrid / pointInGrid, src/frame.cpp:304-367). */
+typedef struct {
+    float min_x, min_y, max_x, max_y; /* Camera::minX() ... (src/geometry/camera.cpp:149-158) */
+    int32_t grid_cols, grid_rows;     /* /orb_slam/tracker/grid_cols, grid_rows */
+    int32_t grid_size_x, grid_size_y; /* undistWidth()/grid_cols, undistHeight()/grid_rows as int (frame.cpp:309-310) */
+} orbx_grid;
+
+/* Makes orbx_extract_batch follow MonoFrame::extractFeatures (src/mono_frame.cpp:72-110) step by step: after
+   detect the keypoints are undistorted (camera != NULL and k1 != 0, camera.cpp:101), bucketed and filtered by
+   Frame::assignFeaturesToGrid (grid != NULL), and described at the undistorted coordinates.  NULL clears. */
+orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera* camera, const orbx_grid* grid);
+
+/* Camera::undistortPoints on n (x,y) float pairs; host arithmetic in double as cv::undistortPoints. */
+orbx_status orbx_undistort_points(const orbx_camera* camera, const float* xy_in, int n, float* xy_out);
+
+/* Device views of the per-frame bucket grids of the last orbx_extract_batch (set_frame_model with a grid):
+   cell_start int32[frames][cols*rows + 1], cell_items int32[frames][kp_capacity]. */
+orbx_status orbx_extractor_device_grid(orbx_extractor* h, const int32_t** d_cell_start, const int32_t** d_cell_items);
+
 /* Device views of the last orbx_extract_batch: keypoints (orbx_keypoint[frames][kp_capacity]),
    descriptors (uint8[frames][kp_capacity][32]), counts (int32[frames]). */
 orbx_status orbx_extractor_device_results(orbx_extractor* h, const orbx_keypoint** d_keypoints,
@@ -134,12 +157,6 @@ orbx_status orbx_match_radius(orbx_matcher* h, const orbx_keypoint* keypoints, i
                               int n_ref, const uint8_t* descriptors, const uint8_t* ref_descriptors,
                               double max_pixel_dist, orbx_match* matches, int* count);
 
-/* Frame bucket grid (Frame::setupGrid / assignFeaturesToGrid / pointInGrid, src/frame.cpp:304-367). */
-typedef struct {
-    float min_x, min_y, max_x, max_y; /* Camera::minX() ... (src/geometry/camera.cpp:149-158) */
-    int32_t grid_cols, grid_rows;     /* /orb_slam/tracker/grid_cols, grid_rows */
-    int32_t grid_size_x, grid_size_y; /* undistWidth()/grid_cols, undistHeight()/grid_rows as int (frame.cpp:309-310) */
-} orbx_grid;
 /* Replaces Frame::assignFeaturesToGrid: drops out-of-grid keypoints in place (*count updated) and writes the
    cells in grid_[col][row] order as CSR: cell_start[cols*rows + 1], cell_items[*count]. */
 orbx_status orbx_assign_grid(const orbx_grid* g, orbx_keypoint* keypoints, int* count, int32_t* cell_start,
@@ -159,6 +176,23 @@ orbx_status orbx_match_projection_frame(orbx_matcher* h, const orbx_grid* g, con
                                         const uint8_t* ref_descriptors, const float* scale_factors, int n_levels,
                                         int level_mode, float radius, int check_orientation,
                                         orbx_match* matches, int* count);
+
+/* Batched form of orbx_match_projection_frame on the device results of an extractor (orbx_extract_batch with a
+   frame model): pair p matches frame d_frame_index[p] against reference frame d_ref_index[p].  The reference
+   features are the keypoints of the reference frame, their best descriptors its descriptors.  d_proj_xy
+   [pairs][kp_capacity][2] = projection of every reference feature into the frame; d_ref_has_point / d_proj_z
+   [pairs][kp_capacity] may be NULL (every feature has a point / depth positive).  Outputs (device):
+   d_matched [pairs][kp_capacity] = reference index matched to each frame feature (<= 0: none, as the reference's
+   `matched` vector), d_distance likewise, d_n_matches [pairs] = number of entries createMatches would emit. */
+orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* g, int n_pairs,
+                                              const int32_t* d_frame_index, const int32_t* d_ref_index,
+                                              const orbx_keypoint* d_keypoints, const uint8_t* d_descriptors,
+                                              const int32_t* d_counts, int kp_capacity,
+                                              const int32_t* d_cell_start, const int32_t* d_cell_items,
+                                              const uint8_t* d_ref_has_point, const float* d_proj_xy,
+                                              const float* d_proj_z, const float* scale_factors, int n_levels,
+                                              int level_mode, float radius, int check_orientation,
+                                              int32_t* d_matched, int32_t* d_distance, int32_t* d_n_matches);
 
 /* Replaces BruteForceWithProjectionMatcher::match(frame, points_3d, matches) (orb_matcher.cpp:257-352) with the
    track properties (Frame::isInCameraView, frame.cpp:220-268) supplied by the caller. */

@@ -57,6 +57,12 @@ struct orbx_extractor {
     PinBuf<int> h_ints;
     PinBuf<orbx_keypoint> h_kp;
     PinBuf<uint8_t> h_desc;
+    // optional frame model of MonoFrame::extractFeatures for the batch path
+    bool has_camera = false, has_grid = false;
+    orbx_camera camera;
+    orbx_grid grid;
+    DevBuf<int32_t> d_cell_start, d_cell_items;
+    PinBuf<int32_t> h_cell_start, h_cell_items;
     int last_frames = 0;
     bool pyramid_valid = false;  // atlas holds the pyramid of the frames of the last detect stage
 
@@ -437,6 +443,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
     h->d_kp_counts.release(); h->d_kp.release();
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();
+    h->d_cell_start.release(); h->d_cell_items.release(); h->h_cell_start.release(); h->h_cell_items.release();
     h->timer.destroy();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -574,9 +581,46 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels));
     std::vector<std::vector<orbx_keypoint>> sel;
     ORBX_TRY(select_keypoints(h, n_frames, sel));
+    // MonoFrame::extractFeatures between detect and compute (mono_frame.cpp:85-100): undistort, bucket, filter
+    const int ncell = h->has_grid ? h->grid.grid_cols * h->grid.grid_rows : 0;
+    if (h->has_grid) {
+        ORBX_TRY(h->h_cell_start.ensure((size_t)(ncell + 1) * n_frames));
+        ORBX_TRY(h->h_cell_items.ensure((size_t)capacity * n_frames));
+    }
     int max_n = 0;
     for (auto& v : sel) max_n = std::max(max_n, (int)v.size());
     if (max_n > capacity) return ORBX_CAPACITY;
+    if (h->has_camera || h->has_grid) {
+        auto work = [&](int f0, int f1) {
+            std::vector<float> xy;
+            for (int f = f0; f < f1; f++) {
+                auto& k = sel[f];
+                if (h->has_camera && h->camera.k1 != 0.0 && !k.empty()) {
+                    xy.resize(k.size() * 2);
+                    for (size_t i = 0; i < k.size(); i++) { xy[2 * i] = k[i].x; xy[2 * i + 1] = k[i].y; }
+                    host::undistort_points(h->camera, xy.data(), (int)k.size(), xy.data());
+                    for (size_t i = 0; i < k.size(); i++) { k[i].x = xy[2 * i]; k[i].y = xy[2 * i + 1]; }
+                }
+                if (h->has_grid) {
+                    int cnt = (int)k.size();
+                    (void)orbx_assign_grid(&h->grid, k.data(), &cnt, h->h_cell_start.p + (size_t)f * (ncell + 1),
+                                           h->h_cell_items.p + (size_t)f * capacity);
+                    k.resize(cnt);
+                }
+                // cv::ORB::compute drops keypoints whose rounded position is within the border (it may, after
+                // undistortion); the grid built above then refers to the unfiltered list, as in the reference.
+            }
+        };
+        int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        nthreads = std::min(nthreads, n_frames);
+        std::vector<std::thread> th;
+        int per = div_up(n_frames, nthreads);
+        for (int t = 0; t < nthreads; t++) {
+            int f0 = t * per, f1 = std::min(n_frames, f0 + per);
+            if (f0 < f1) th.emplace_back(work, f0, f1);
+        }
+        for (auto& t : th) t.join();
+    }
     h->kp_cap = capacity;
     ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
     ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
@@ -584,12 +628,22 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(h->h_kp.ensure((size_t)capacity * n_frames));
     int* h_counts = h->h_ints.p;
     for (int f = 0; f < n_frames; f++) {
+        // cv::ORB::compute: runByImageBorder on the (possibly moved) keypoints; octaves are already ascending
+        if (h->has_camera) host::run_by_image_border(sel[f], width, height, h->prm.edge_threshold);
         h_counts[f] = (int)sel[f].size();
         std::copy(sel[f].begin(), sel[f].end(), h->h_kp.p + (size_t)f * capacity);
     }
     ORBX_HIP(hipMemcpyAsync(h->d_kp.p, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
                             hipMemcpyHostToDevice, h->stream));
     ORBX_HIP(hipMemcpyAsync(h->d_kp_counts.p, h_counts, sizeof(int) * n_frames, hipMemcpyHostToDevice, h->stream));
+    if (h->has_grid) {
+        ORBX_TRY(h->d_cell_start.ensure((size_t)(ncell + 1) * n_frames));
+        ORBX_TRY(h->d_cell_items.ensure((size_t)capacity * n_frames));
+        ORBX_HIP(hipMemcpyAsync(h->d_cell_start.p, h->h_cell_start.p, sizeof(int32_t) * (size_t)(ncell + 1) * n_frames,
+                                hipMemcpyHostToDevice, h->stream));
+        ORBX_HIP(hipMemcpyAsync(h->d_cell_items.p, h->h_cell_items.p, sizeof(int32_t) * (size_t)capacity * n_frames,
+                                hipMemcpyHostToDevice, h->stream));
+    }
     ORBX_TRY(run_describe_stage(h, n_frames));
     if (descriptors)
         ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost,
@@ -598,6 +652,26 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     collect_timings(h);
     if (counts) std::memcpy(counts, h_counts, sizeof(int) * n_frames);
     if (keypoints) std::memcpy(keypoints, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames);
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera* camera, const orbx_grid* grid) {
+    if (!h) return ORBX_BAD_ARG;
+    if (grid && (grid->grid_cols <= 0 || grid->grid_rows <= 0 || grid->grid_size_x <= 0 || grid->grid_size_y <= 0 ||
+                 (long long)grid->grid_cols * grid->grid_rows > (1 << 20)))
+        return ORBX_BAD_ARG;
+    if (camera && (!(camera->fx != 0.0) || !(camera->fy != 0.0))) return ORBX_BAD_ARG;
+    h->has_camera = camera != nullptr;
+    h->has_grid = grid != nullptr;
+    if (camera) h->camera = *camera;
+    if (grid) h->grid = *grid;
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_device_grid(orbx_extractor* h, const int32_t** d_cell_start, const int32_t** d_cell_items) {
+    if (!h || !h->has_grid) return ORBX_BAD_ARG;
+    if (d_cell_start) *d_cell_start = h->d_cell_start.p;
+    if (d_cell_items) *d_cell_items = h->d_cell_items.p;
     return ORBX_OK;
 }
 

@@ -99,6 +99,26 @@ void scale_tables(float scale_factor, int nlevels, float* sf, float* isf, float*
     if (log_sf) *log_sf = (float)std::log((double)scale_factor);
 }
 
+void undistort_points(const orbx_camera& c, const float* xy_in, int n, float* xy_out) {
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    for (int i = 0; i < n; i++) {
+        double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+        x = (x - c.cx) * ifx;
+        y = (y - c.cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+            const double dx = 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x);
+            const double dy = c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        xy_out[2 * i] = (float)(x * c.fx + c.cx);
+        xy_out[2 * i + 1] = (float)(y * c.fy + c.cy);
+    }
+}
+
 }  // namespace host
 }  // namespace orbx
 
@@ -124,6 +144,12 @@ orbx_status orbx_filter_matches(orbx_match* matches, int* count, int n_descripto
         if (good[i].train != good[i - 1].train) out.push_back(good[i]);
     std::copy(out.begin(), out.end(), matches);
     *count = (int)out.size();
+    return ORBX_OK;
+}
+
+orbx_status orbx_undistort_points(const orbx_camera* camera, const float* xy_in, int n, float* xy_out) {
+    if (!camera || n < 0 || (n > 0 && (!xy_in || !xy_out))) return ORBX_BAD_ARG;
+    orbx::host::undistort_points(*camera, xy_in, n, xy_out);
     return ORBX_OK;
 }
 

@@ -29,5 +29,9 @@ void select_keypoints(const Cand* cands, int n, const int* level_counts, int nle
 // ORBExtractor's own tables (reference include/orb_slam/geometry/orb_extractor.h:39-54).
 void scale_tables(float scale_factor, int nlevels, float* sf, float* isf, float* ss, float* iss, float* log_sf);
 
+// cv::undistortPoints with P = K as Camera::undistortPoints calls it (reference src/geometry/camera.cpp:97-126):
+// 5 fixed-point iterations of the inverse Brown model in double, re-projected with the same intrinsics.
+void undistort_points(const orbx_camera& c, const float* xy_in, int n, float* xy_out);
+
 }  // namespace host
 }  // namespace orbx

@@ -135,6 +135,13 @@ __global__ __launch_bounds__(256) void k_bf_sad_radius(const uint8_t* __restrict
 
 struct ProjArgs {
     orbx_grid g;
+    // per-frame arrays; the single-pair entry points use stride 0 and no index arrays
+    const int32_t* frame_index;  // [pairs] or NULL (frame 0)
+    const int32_t* ref_index;    // [pairs] or NULL (reference 0)
+    const int32_t* counts;       // features per frame, or NULL (n / n_ref below)
+    size_t kp_stride;            // keypoints (and cell items) per frame slot
+    size_t cell_stride;          // cell_start entries per frame slot
+    size_t pair_stride;          // entries per pair in the per-pair arrays
     const int32_t* cell_start;
     const int32_t* cell_items;
     const orbx_keypoint* kps;   // frame features
@@ -142,9 +149,9 @@ struct ProjArgs {
     const uint8_t* desc;        // frame descriptors
     const orbx_keypoint* ref_kps;  // mode 0: reference features (octave, angle); mode 1: unused
     int n_ref;
-    const uint8_t* ref_flag;    // mode 0: has map point; mode 1: in view
+    const uint8_t* ref_flag;    // mode 0: has map point; mode 1: in view; NULL = all set
     const float* proj_xy;
-    const float* proj_z;        // mode 0 only
+    const float* proj_z;        // mode 0 only; NULL = positive
     const int32_t* pred_level;  // mode 1 only
     const float* view_cos;      // mode 1 only
     const uint8_t* ref_desc;
@@ -154,10 +161,11 @@ struct ProjArgs {
     float radius;
     float nn_ratio;
     int check_orientation;
-    int32_t* matched;           // out [n]
-    int32_t* dists;             // out [n]
-    int32_t* pushes;            // scratch [n_ref * 2]: (bin, feature) of every histogram push
-    int32_t* status;            // out: 1 = a window held more than kListCap candidates
+    int32_t* matched;           // out [pairs][pair_stride]
+    int32_t* dists;             // out [pairs][pair_stride]
+    int32_t* pushes;            // scratch [pairs][2 * pair_stride]: (bin, feature) of every histogram push
+    int32_t* status;            // out [pairs]: 1 = a window held more than kListCap candidates
+    int32_t* n_matches;         // out [pairs] or NULL
 };
 
 __device__ __forceinline__ int hamming32(const uint8_t* a, const uint8_t* b) {
@@ -181,22 +189,53 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     __shared__ int32_t s_hist[30];
     const int lane = threadIdx.x;
     const orbx_grid g = A.g;
-    for (int i = lane; i < A.n; i += 64) {
-        s_matched[i] = -1;
-        A.dists[i] = -1;
+    {
+        // resolve this pair's views
+        const int pair = blockIdx.x;
+        const int fi = A.frame_index ? A.frame_index[pair] : 0;
+        const int ri = A.ref_index ? A.ref_index[pair] : 0;
+        A.n = A.counts ? A.counts[fi] : A.n;
+        A.n_ref = A.counts ? A.counts[ri] : A.n_ref;
+        A.kps += (size_t)fi * A.kp_stride;
+        A.desc += (size_t)fi * A.kp_stride * 32;
+        A.cell_start += (size_t)fi * A.cell_stride;
+        A.cell_items += (size_t)fi * A.kp_stride;
+        if (A.ref_kps) A.ref_kps += (size_t)ri * A.kp_stride;
+        A.ref_desc += (size_t)ri * A.kp_stride * 32;
+        const size_t po = (size_t)pair * A.pair_stride;
+        if (A.ref_flag) A.ref_flag += po;
+        A.proj_xy += po * 2;
+        if (A.proj_z) A.proj_z += po;
+        if (A.pred_level) A.pred_level += po;
+        if (A.view_cos) A.view_cos += po;
+        A.matched += po;
+        A.dists += po;
+        A.pushes += po * 2;
+        A.status += pair;
+        if (A.n_matches) A.n_matches += pair;
+        A.n = min(A.n, kMaxFeatures);
+    }
+    {
+        // flags cover the whole frame slot in the batched form: a stale grid entry (the reference's compute() may
+        // erase keypoints after the grid was built) then reads "unmatched", never uninitialised memory
+        const int n_init = A.kp_stride ? (int)A.kp_stride : A.n;
+        for (int i = lane; i < n_init; i += 64) {
+            s_matched[i] = -1;
+            if (i < A.n || A.kp_stride) A.dists[i] = -1;
+        }
     }
     if (lane < 30) s_hist[lane] = 0;
     __syncthreads();
     int n_push = 0;
     const float factor = 1.0f / 30;
     for (int ref_idx = 0; ref_idx < A.n_ref; ++ref_idx) {
-        if (!A.ref_flag[ref_idx]) continue;
+        if (A.ref_flag && !A.ref_flag[ref_idx]) continue;
         const float px = A.proj_xy[2 * ref_idx], py = A.proj_xy[2 * ref_idx + 1];
         int level, min_level, max_level;
         bool min_only = false;
         float radius_scaled;
         if (MODE == 0) {
-            if (A.proj_z[ref_idx] < 0) continue;
+            if (A.proj_z && A.proj_z[ref_idx] < 0) continue;
             if (!(px > g.min_x && px < g.max_x && py > g.min_y && py < g.max_y)) continue;
             level = A.ref_kps[ref_idx].octave;
             if (level < 0 || level >= A.n_levels) continue;
@@ -332,7 +371,15 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
         }
         __syncthreads();
     }
-    for (int i = lane; i < A.n; i += 64) A.matched[i] = s_matched[i];
+    int cnt = 0;
+    for (int i = lane; i < A.n; i += 64) {
+        const int m = s_matched[i];
+        A.matched[i] = m;
+        cnt += m > 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0 && A.n_matches) *A.n_matches = cnt;
 }
 
 }  // namespace
@@ -542,6 +589,7 @@ static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g,
         if (cell_items[i] < 0 || cell_items[i] >= n) return ORBX_BAD_ARG;
 
     ProjArgs A;
+    std::memset(&A, 0, sizeof(A));
     A.g = *g;
     A.cell_start = h->d_cells.p;
     A.cell_items = h->d_items.p;
@@ -566,6 +614,7 @@ static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g,
     A.dists = h->d_dist.p;
     A.pushes = h->d_pushes.p;
     A.status = d_status;
+    A.n_matches = nullptr;
     const size_t shmem = sizeof(int32_t) * (size_t)n;
     if (mode == 0) hipLaunchKernelGGL(k_projection_match<0>, dim3(1), dim3(64), shmem, s, A);
     else hipLaunchKernelGGL(k_projection_match<1>, dim3(1), dim3(64), shmem, s, A);
@@ -595,6 +644,61 @@ orbx_status orbx_match_projection_frame(orbx_matcher* h, const orbx_grid* g, con
     return run_projection(h, 0, g, cell_start, cell_items, keypoints, n, descriptors, ref_keypoints, n_ref,
                           ref_has_point, proj_xy, proj_z, nullptr, nullptr, ref_descriptors, scale_factors, n_levels,
                           level_mode, radius, 0.f, check_orientation, matches, count);
+}
+
+orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* g, int n_pairs,
+                                              const int32_t* d_frame_index, const int32_t* d_ref_index,
+                                              const orbx_keypoint* d_keypoints, const uint8_t* d_descriptors,
+                                              const int32_t* d_counts, int kp_capacity,
+                                              const int32_t* d_cell_start, const int32_t* d_cell_items,
+                                              const uint8_t* d_ref_has_point, const float* d_proj_xy,
+                                              const float* d_proj_z, const float* scale_factors, int n_levels,
+                                              int level_mode, float radius, int check_orientation,
+                                              int32_t* d_matched, int32_t* d_distance, int32_t* d_n_matches) {
+    if (!h || !g || n_pairs <= 0 || !d_frame_index || !d_ref_index || !d_keypoints || !d_descriptors || !d_counts ||
+        !d_cell_start || !d_cell_items || !d_proj_xy || !scale_factors || !d_matched || !d_distance)
+        return ORBX_BAD_ARG;
+    if (kp_capacity <= 0 || n_levels <= 0 || n_levels > 64) return ORBX_BAD_ARG;
+    if (g->grid_cols <= 0 || g->grid_rows <= 0 || g->grid_size_x <= 0 || g->grid_size_y <= 0) return ORBX_BAD_ARG;
+    if (kp_capacity > kMaxFeatures) return ORBX_CAPACITY;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_f2.ensure(n_levels));
+    ORBX_TRY(h->d_pushes.ensure((size_t)2 * kp_capacity * n_pairs));
+    ORBX_TRY(h->d_ints.ensure(n_pairs));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_factors, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemsetAsync(h->d_ints.p, 0, sizeof(int32_t) * n_pairs, s));
+    ProjArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.g = *g;
+    A.frame_index = d_frame_index;
+    A.ref_index = d_ref_index;
+    A.counts = d_counts;
+    A.kp_stride = kp_capacity;
+    A.cell_stride = (size_t)g->grid_cols * g->grid_rows + 1;
+    A.pair_stride = kp_capacity;
+    A.cell_start = d_cell_start;
+    A.cell_items = d_cell_items;
+    A.kps = d_keypoints;
+    A.desc = d_descriptors;
+    A.ref_kps = d_keypoints;
+    A.ref_flag = d_ref_has_point;
+    A.proj_xy = d_proj_xy;
+    A.proj_z = d_proj_z;
+    A.ref_desc = d_descriptors;
+    A.scale_factors = h->d_f2.p;
+    A.n_levels = n_levels;
+    A.level_mode = level_mode;
+    A.radius = radius;
+    A.check_orientation = check_orientation;
+    A.matched = d_matched;
+    A.dists = d_distance;
+    A.pushes = h->d_pushes.p;
+    A.status = h->d_ints.p;
+    A.n_matches = d_n_matches;
+    hipLaunchKernelGGL(k_projection_match<0>, dim3(n_pairs), dim3(64), sizeof(int32_t) * (size_t)kp_capacity, s, A);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
 }
 
 orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,

@@ -26,7 +26,8 @@ SYMBOLS = [
     "orbx_match_hamming_batch", "orbx_filter_matches", "orbx_match_radius", "orbx_assign_grid",
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
-    "orbx_ransac_last_timings", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+    "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
 
@@ -41,6 +42,23 @@ class Grid(C.Structure):
     _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
                 ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("grid_size_x", C.c_int32),
                 ("grid_size_y", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("k3", C.c_double)]
+
+
+def make_camera(fx, fy, cx, cy, dist):
+    f = lambda v: float(np.float32(v))  # the reference keeps intrinsics and distortion in cv::Mat_<float>
+    return Camera(f(fx), f(fy), f(cx), f(cy), *[f(v) for v in dist])
+
+
+def undistort_points(cam, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    _check(lib().orbx_undistort_points(C.byref(cam), _p(xy), len(xy), _p(out)), "orbx_undistort_points")
+    return out
 
 
 class OrbxError(RuntimeError):
@@ -195,6 +213,16 @@ class Extractor:
                "orbx_extract_batch")
         return kps, counts, desc
 
+    def set_frame_model(self, camera=None, grid=None):
+        _check(lib().orbx_extractor_set_frame_model(self._h, C.byref(camera) if camera is not None else None,
+                                                    C.byref(grid) if grid is not None else None),
+               "orbx_extractor_set_frame_model")
+
+    def device_grid(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().orbx_extractor_device_grid(self._h, C.byref(a), C.byref(b)), "orbx_extractor_device_grid")
+        return a.value, b.value
+
     def device_results(self):
         kp, desc, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
         cap = C.c_int()
@@ -290,6 +318,17 @@ class Matcher:
                                                  C.c_float(radius), int(check_orientation), _p(out), C.byref(n)),
                "orbx_match_projection_frame")
         return out[:n.value].copy()
+
+    def match_projection_frame_batch(self, g, n_pairs, d_frame_index, d_ref_index, d_kp, d_desc, d_counts, kp_cap,
+                                     d_cell_start, d_cell_items, d_has, d_proj_xy, d_proj_z, scale_factors,
+                                     level_mode, radius, check_orientation, d_matched, d_dist, d_n_matches):
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        _check(lib().orbx_match_projection_frame_batch(
+            self._h, C.byref(g), n_pairs, C.c_void_p(d_frame_index), C.c_void_p(d_ref_index), C.c_void_p(d_kp),
+            C.c_void_p(d_desc), C.c_void_p(d_counts), kp_cap, C.c_void_p(d_cell_start), C.c_void_p(d_cell_items),
+            C.c_void_p(d_has), C.c_void_p(d_proj_xy), C.c_void_p(d_proj_z), _p(sf), len(sf), level_mode,
+            C.c_float(radius), int(check_orientation), C.c_void_p(d_matched), C.c_void_p(d_dist),
+            C.c_void_p(d_n_matches)), "orbx_match_projection_frame_batch")
 
     def match_projection_points(self, g, start, items, kps, desc, in_view, proj_xy, pred_level, view_cos, pt_desc,
                                 scale_factors, radius, nn_ratio):
