@@ -141,7 +141,11 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one non-default stream for torch's plumbing AND the library's kernels (a NULL stream handle means "the
+    # handle's own stream" to orbx_*_set_stream)
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
 
     B = args.frames
     base = np.load(os.path.join(ROOT, "tests", "golden", "test_images.npz"))["bgr1"]

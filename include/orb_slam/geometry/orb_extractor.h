@@ -1,0 +1,141 @@
+/*
+ * Drop-in replacement of the reference's include/orb_slam/geometry/orb_extractor.h: same class, namespace,
+ * constructor, getters and detect/compute signatures (reference orb_extractor.h:25-150); the two cv::ORB objects
+ * are replaced by one orbx_extractor handle (include/orbx.h), i.e. by the gfx950 kernels.
+ */
+#pragma once
+
+#include <iostream>
+#include <string>
+
+#include <orb_slam/orbx_compat.h>
+
+namespace orb_slam
+{
+
+namespace geometry
+{
+
+class ORBExtractor
+{
+public:
+    ORBExtractor(const ros::NodeHandle& nh, int max_width = 1920, int max_height = 1080, int device = 0): nh_(nh) {
+        std::string prefix = "orb_slam/orb_extractor/";
+        // same keys and defaults as the reference (orb_extractor.h:29-37)
+        nh_.param<int>(prefix + "n_key_points", n_key_points_, 8000);
+        nh_.param<float>(prefix + "scale_factor", scale_factor_, 1.200000048F);
+        nh_.param<int>(prefix + "level_pyramid", level_pyramid_, 4);
+        nh_.param<int>(prefix + "edge_threshold", edge_threshold_, 31);
+        nh_.param<int>(prefix + "first_level", first_level_, 0);
+        nh_.param<int>(prefix + "wta_k", wta_k_, 2);
+        nh_.param<int>(prefix + "patch_size", patch_size_, 31);
+        nh_.param<int>(prefix + "score_threshold", score_threshold_, 20);
+
+        orbx_extractor_params p = {
+            n_key_points_, scale_factor_, level_pyramid_, edge_threshold_, first_level_, wta_k_, patch_size_,
+            score_threshold_};
+        orbx_extractor* h = nullptr;
+        orbx_compat::check(orbx_extractor_create(&p, max_width, max_height, 1, device, &h), "ORBExtractor");
+        handle_ = std::shared_ptr<orbx_extractor>(h, orbx_extractor_destroy);
+
+        scale_factors_.resize(level_pyramid_);
+        scale_sigma_sqrd_.resize(level_pyramid_);
+        inv_scale_factors_.resize(level_pyramid_);
+        inv_scale_sigma_sqrd_.resize(level_pyramid_);
+        orbx_extractor_scale_tables(
+            h, scale_factors_.data(), inv_scale_factors_.data(), scale_sigma_sqrd_.data(),
+            inv_scale_sigma_sqrd_.data(), &log_scale_factor_);
+    }
+
+    /**
+     * Getters
+     */
+    const float& scaleFactor() const { return scale_factor_;}
+    const float& logScaleFactor() const { return log_scale_factor_;}
+    const std::vector<float>& scaleFactors() const { return scale_factors_; }
+    const int& levels() const { return level_pyramid_; }
+    const std::vector<float>& scaleSigmas() const { return scale_sigma_sqrd_; }
+    const std::vector<float>& invScaleSigmas() const
+        { return inv_scale_sigma_sqrd_; }
+
+    /**
+     * Extracts orb features from the input image (8UC1 or 8UC3 BGR)
+     */
+    void detect(
+        const cv::Mat& image, std::vector<cv::KeyPoint>& key_points) const
+    {
+        key_points.clear();
+        if (image.empty()) return; // cv::ORB returns silently on an empty image
+        int capacity = 4 * n_key_points_ + 4096, count = 0;
+        for (;;) {
+            key_points.resize(capacity);
+            orbx_status s = orbx_detect(
+                handle_.get(), image.data, image.cols, image.rows, (int)image.step, image.channels(),
+                reinterpret_cast<orbx_keypoint*>(key_points.data()), capacity, &count);
+            if (s == ORBX_CAPACITY && count > capacity) { capacity = count; continue; }
+            orbx_compat::check(s, "ORBExtractor::detect");
+            break;
+        }
+        key_points.resize(count);
+    }
+
+    /**
+     * Computes orb descriptors from the input image and key points
+     */
+    void compute(
+        const cv::Mat& image,
+        std::vector<cv::KeyPoint>& key_points,
+        cv::Mat& descriptors) const
+    {
+        if (image.empty() || key_points.empty()) { descriptors.release(); return; }
+        int count = (int)key_points.size();
+        cv::Mat d(count, 32, CV_8U);
+        orbx_compat::check(
+            orbx_compute(
+                handle_.get(), image.data, image.cols, image.rows, (int)image.step, image.channels(),
+                reinterpret_cast<orbx_keypoint*>(key_points.data()), &count, d.data),
+            "ORBExtractor::compute");
+        key_points.resize(count);
+        if (count == 0) { descriptors.release(); return; }
+        if (count == d.rows) descriptors = d;
+        else {
+            descriptors = cv::Mat(count, 32, CV_8U);
+            std::memcpy(descriptors.data, d.data, (size_t)count * 32);
+        }
+    }
+
+    ~ORBExtractor() {
+
+    }
+
+private:
+    //! parameter source
+    ros::NodeHandle nh_;
+
+    //! orb extractor parameters
+    int n_key_points_; // number of key points to extract
+    float log_scale_factor_; // log of scale factor
+    float scale_factor_; // feature scale factor
+    int level_pyramid_; // image pyramid level
+    int edge_threshold_ = {31}; // edge threshold
+    int first_level_ = {0}; // first level
+    int wta_k_ = {2}; // wta_k
+    int patch_size_ = {31}; // patch size
+    int score_threshold_; // score threshold
+
+    std::vector<float> scale_factors_;
+    std::vector<float> inv_scale_factors_;
+    std::vector<float> scale_sigma_sqrd_;
+    std::vector<float> inv_scale_sigma_sqrd_;
+
+    //! device-side extractor (replaces the two cv::ORB objects)
+    std::shared_ptr<orbx_extractor> handle_;
+    std::string name_tag_ = {"ORBExtractor"};
+};
+
+using ORBExtractorPtr = std::shared_ptr<ORBExtractor>;
+using ORBExtractorConstPtr = std::shared_ptr<const ORBExtractor>;
+
+} // namespace geometry
+
+} // namespace orb_slam

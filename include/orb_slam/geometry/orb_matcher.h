@@ -1,0 +1,188 @@
+/*
+ * Drop-in counterpart of the reference's ORBMatcher facade (include/orb_slam/geometry/orb_matcher.h:342-470,
+ * src/geometry/orb_matcher.cpp:679-791,890-924) on top of the C ABI in include/orbx.h.
+ *
+ * match() x2 and filterMatches() keep the reference signatures.  The projection matchers of the reference take
+ * FramePtr / MapPointPtr, types that live outside this path; here they are templates over any frame type that
+ * offers the accessors the reference's Frame has (featuresUndist(), descriptorsUndist(), obsMapPoints(),
+ * worldToCamera<float>(), cameraToFrame<float,float>(), camera(), orbExtractor()), so the tracker's call sites
+ * (src/frame.cpp:394-422) compile unchanged against them.
+ */
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <orb_slam/geometry/utils.h>
+#include <orb_slam/orbx_compat.h>
+
+namespace orb_slam
+{
+
+namespace geometry
+{
+
+//! Types of matchers (same enumerators as the reference)
+enum OrbMatcherTypes {
+    BF_WITH_RADIUS,
+    BF_WITH_PROJ,
+    BOW_ORB,
+    EPIPOLAR_CONSTRAINT,
+    CV_ORB,
+    MATCHER_TYPES
+};
+
+class ORBMatcher {
+public:
+    ORBMatcher(const ros::NodeHandle& nh, int device = 0): nh_(nh) {
+        nh_.getParam("orb_slam/orb_matcher/method", method_); // read and, as in the reference, not used
+        nh_.getParam("orb_slam/brute_force_with_radius/max_matching_pixel_dist", max_matching_pixel_dist_);
+        std::string type = "BruteForce-Hamming";
+        nh_.getParam("orb_slam/cv_orb_matcher/type", type);
+        if (type != "BruteForce-Hamming")
+            throw std::runtime_error("ORBMatcher: only cv_orb_matcher/type BruteForce-Hamming is implemented");
+        orbx_matcher* h = nullptr;
+        orbx_compat::check(orbx_matcher_create(device, &h), "ORBMatcher");
+        handle_ = std::shared_ptr<orbx_matcher>(h, orbx_matcher_destroy);
+    }
+
+    ~ORBMatcher() {}
+
+    /** BruteForceWithRadiusMatcher path (orb_matcher.cpp:699-717). */
+    void match(
+        const std::vector<cv::KeyPoint>& key_points,
+        const std::vector<cv::KeyPoint>& ref_key_points,
+        const cv::Mat& descriptors,
+        const cv::Mat& ref_descriptors,
+        std::vector<cv::DMatch>& matches,
+        bool filter_matches = true) const
+    {
+        std::vector<cv::DMatch> out(key_points.size());
+        int count = 0;
+        orbx_compat::check(
+            orbx_match_radius(
+                handle_.get(),
+                reinterpret_cast<const orbx_keypoint*>(key_points.data()), (int)key_points.size(),
+                reinterpret_cast<const orbx_keypoint*>(ref_key_points.data()), (int)ref_key_points.size(),
+                descriptors.data, ref_descriptors.data, max_matching_pixel_dist_,
+                reinterpret_cast<orbx_match*>(out.data()), &count),
+            "ORBMatcher::match(radius)");
+        out.resize(count);
+        matches.insert(matches.end(), out.begin(), out.end()); // the reference push_backs
+        if (filter_matches) filterMatches(descriptors, matches);
+    }
+
+    /** CVORBMatcher path = cv::BFMatcher(NORM_HAMMING) (orb_matcher.cpp:719-733). */
+    void match(
+        const cv::Mat& descriptors,
+        const cv::Mat& ref_descriptors,
+        std::vector<cv::DMatch>& matches,
+        bool filter_matches = true) const
+    {
+        const int n = descriptors.rows;
+        std::vector<int32_t> idx(n), dist(n);
+        orbx_compat::check(
+            orbx_match_hamming(
+                handle_.get(), descriptors.data, n, ref_descriptors.data, ref_descriptors.rows,
+                idx.data(), dist.data()),
+            "ORBMatcher::match(hamming)");
+        matches.clear();
+        if (ref_descriptors.rows == 0) return;
+        matches.reserve(n);
+        for (int i = 0; i < n; ++i) {
+            cv::DMatch m(i, idx[i], (float)dist[i]);
+            m.imgIdx = 0; // cv::BFMatcher reports the index of the train image
+            matches.push_back(m);
+        }
+        if (filter_matches) filterMatches(descriptors, matches);
+    }
+
+    /** Frame-to-frame projection matcher (orb_matcher.cpp:748-761, 76-93, 115-255). */
+    template <typename FramePtrT>
+    void matchByProjection(
+        const FramePtrT& frame,
+        const FramePtrT& ref_frame,
+        std::vector<cv::DMatch>& matches,
+        const bool check_orientation = true,
+        const float radius = 1.0) const
+    {
+        const auto& key_points = frame->featuresUndist();
+        const auto& ref_key_points = ref_frame->featuresUndist();
+        const cv::Mat& descriptors = frame->descriptorsUndist();
+        const auto& ref_map_points = ref_frame->obsMapPoints();
+        const cv::Mat ref_T_f = ref_frame->worldInCameraT() * frame->cameraInWorldT();
+        const float z = ref_T_f.template at<float>(2, 3);
+        const int level_mode = z > 0.1f ? 1 : (-z > 0.1f ? 2 : 0);
+        const int n = (int)key_points.size(), n_ref = (int)ref_key_points.size();
+        std::vector<uint8_t> has(n_ref, 0);
+        std::vector<float> xy(2 * (size_t)n_ref, 0.f), depth(n_ref, 1.f);
+        cv::Mat ref_desc(n_ref, 32, CV_8U);
+        for (int i = 0; i < n_ref; ++i) {
+            const auto& mp = ref_map_points[i];
+            if (!mp) continue;
+            has[i] = 1;
+            auto pc = frame->template worldToCamera<float>(mp->worldPos());
+            depth[i] = pc.z;
+            auto px = frame->template cameraToFrame<float, float>(pc);
+            xy[2 * i] = px.x;
+            xy[2 * i + 1] = px.y;
+            std::memcpy(ref_desc.template ptr<uint8_t>(i), mp->bestDescriptor().data, 32);
+        }
+        orbx_grid g = gridOf(frame);
+        std::vector<cv::KeyPoint> kps(key_points);
+        std::vector<int32_t> cell_start((size_t)g.grid_cols * g.grid_rows + 1), cell_items(n);
+        int kept = n;
+        orbx_compat::check(
+            orbx_assign_grid(&g, reinterpret_cast<orbx_keypoint*>(kps.data()), &kept, cell_start.data(), cell_items.data()),
+            "matchByProjection(grid)");
+        const auto& sf = frame->orbExtractor()->scaleFactors();
+        std::vector<cv::DMatch> out(n);
+        int count = 0;
+        orbx_compat::check(
+            orbx_match_projection_frame(
+                handle_.get(), &g, cell_start.data(), cell_items.data(),
+                reinterpret_cast<const orbx_keypoint*>(kps.data()), kept, descriptors.data,
+                reinterpret_cast<const orbx_keypoint*>(ref_key_points.data()), n_ref, has.data(), xy.data(),
+                depth.data(), ref_desc.data, sf.data(), (int)sf.size(), level_mode, radius, check_orientation ? 1 : 0,
+                reinterpret_cast<orbx_match*>(out.data()), &count),
+            "ORBMatcher::matchByProjection");
+        matches.insert(matches.end(), out.begin(), out.begin() + count);
+    }
+
+    /** ORBMatcher::filterMatches (orb_matcher.cpp:890-924). */
+    void filterMatches(
+        const cv::Mat& descriptors,
+        std::vector<cv::DMatch>& matches) const
+    {
+        int count = (int)matches.size();
+        orbx_compat::check(
+            orbx_filter_matches(reinterpret_cast<orbx_match*>(matches.data()), &count, descriptors.rows),
+            "ORBMatcher::filterMatches");
+        matches.resize(count);
+    }
+
+private:
+    template <typename FramePtrT>
+    static orbx_grid gridOf(const FramePtrT& frame) {
+        const auto& cam = frame->camera();
+        orbx_grid g;
+        g.min_x = cam->minX(); g.min_y = cam->minY(); g.max_x = cam->maxX(); g.max_y = cam->maxY();
+        g.grid_cols = frame->gridCols(); g.grid_rows = frame->gridRows();
+        g.grid_size_x = cam->undistWidth() / g.grid_cols;   // int = float / int, Frame::setupGrid
+        g.grid_size_y = cam->undistHeight() / g.grid_rows;
+        return g;
+    }
+
+    ros::NodeHandle nh_;
+    std::string method_;
+    double max_matching_pixel_dist_ = 0.0;
+    std::shared_ptr<orbx_matcher> handle_;
+};
+
+using ORBMatcherPtr = std::shared_ptr<ORBMatcher>;
+using ORBMatcherConstPtr = std::shared_ptr<const ORBMatcher>;
+
+} // namespace geometry
+
+} // namespace orb_slam

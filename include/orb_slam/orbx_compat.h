@@ -1,0 +1,151 @@
+/*
+ * Compatibility layer of the drop-in headers.  With OpenCV and ROS present (the reference's own build) the real
+ * cv:: and ros:: types are used.  Without them (this repository's test builds) minimal stand-ins with the same
+ * member names and memory layout are defined, so the facade classes compile and run unchanged.
+ */
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+
+#if defined(ORBX_WITH_OPENCV) || (defined(__has_include) && __has_include(<opencv2/core/core.hpp>) && !defined(ORBX_NO_OPENCV))
+#include <opencv2/core/core.hpp>
+#include <opencv2/features2d.hpp>
+#define ORBX_HAVE_OPENCV 1
+#else
+#define ORBX_HAVE_OPENCV 0
+#define CV_8U 0
+#define CV_32F 5
+namespace cv {
+template <typename T> struct Point_ {
+    T x, y;
+    Point_() : x(0), y(0) {}
+    Point_(T x_, T y_) : x(x_), y(y_) {}
+};
+typedef Point_<float> Point2f;
+typedef Point_<double> Point2d;
+struct KeyPoint {
+    Point2f pt;
+    float size, angle, response;
+    int octave, class_id;
+    KeyPoint() : size(0), angle(-1), response(0), octave(0), class_id(-1) {}
+};
+struct DMatch {
+    int queryIdx, trainIdx, imgIdx;
+    float distance;
+    DMatch() : queryIdx(-1), trainIdx(-1), imgIdx(-1), distance(3.402823466e+38f) {}
+    DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), imgIdx(-1), distance(d) {}
+};
+/* Dense 2-D matrix with shared storage: the subset of cv::Mat the facade touches. */
+class Mat {
+public:
+    int rows, cols;
+    Mat() : rows(0), cols(0), type_(0), esz_(1) {}
+    Mat(int r, int c, int type) { create(r, c, type); }
+    void create(int r, int c, int type) {
+        rows = r; cols = c; type_ = type & 7; ch_ = ((type >> 3) & 511) + 1;
+        esz_ = (type_ == CV_32F ? 4 : 1) * ch_;
+        buf_ = std::make_shared<std::vector<unsigned char>>((size_t)r * c * esz_);
+        data = buf_->data();
+        step = (size_t)c * esz_;
+    }
+    bool empty() const { return rows == 0 || cols == 0; }
+    int type() const { return type_ | ((ch_ - 1) << 3); }
+    int channels() const { return ch_; }
+    template <typename T> T* ptr(int r = 0) { return (T*)(data + step * r); }
+    template <typename T> const T* ptr(int r = 0) const { return (const T*)(data + step * r); }
+    template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
+    template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+    Mat clone() const { Mat m(rows, cols, type()); if (!empty()) std::memcpy(m.data, data, (size_t)rows * step); return m; }
+    void release() { rows = cols = 0; buf_.reset(); data = nullptr; }
+    unsigned char* data = nullptr;
+    size_t step = 0;
+private:
+    int type_, ch_ = 1, esz_;
+    std::shared_ptr<std::vector<unsigned char>> buf_;
+};
+}  // namespace cv
+#define CV_8UC1 0
+#define CV_8UC3 16
+#endif
+
+#if defined(ORBX_WITH_ROS) || (defined(__has_include) && __has_include(<ros/ros.h>) && !defined(ORBX_NO_ROS))
+#include <ros/ros.h>
+#define ORBX_HAVE_ROS 1
+#else
+#define ORBX_HAVE_ROS 0
+namespace ros {
+/* Parameter source standing in for ros::NodeHandle: a flat key -> scalar map, filled from the reference's own
+   YAML files (cfg/orb_extractor.yaml, cfg/orb_matcher.yaml, cfg/tracker.yaml) with loadYaml(). Keys are the
+   slash-joined paths the reference reads, e.g. "orb_slam/orb_extractor/n_key_points". */
+class NodeHandle {
+public:
+    NodeHandle() : values_(std::make_shared<std::map<std::string, std::string>>()) {}
+    bool loadYaml(const std::string& path) {
+        std::ifstream f(path);
+        if (!f) return false;
+        std::vector<std::pair<int, std::string>> stack;
+        std::string line;
+        while (std::getline(f, line)) {
+            size_t hash = line.find('#');
+            if (hash != std::string::npos) line.erase(hash);
+            size_t first = line.find_first_not_of(" \t\r");
+            if (first == std::string::npos) continue;
+            size_t colon = line.find(':', first);
+            if (colon == std::string::npos) continue;
+            std::string key = line.substr(first, colon - first);
+            std::string val = line.substr(colon + 1);
+            size_t a = val.find_first_not_of(" \t\r\""), b = val.find_last_not_of(" \t\r\"");
+            val = a == std::string::npos ? "" : val.substr(a, b - a + 1);
+            while (!stack.empty() && stack.back().first >= (int)first) stack.pop_back();
+            if (val.empty() || val == "[") { stack.push_back({(int)first, key}); continue; }
+            std::string full;
+            for (auto& s : stack) full += s.second + "/";
+            (*values_)[full + key] = val;
+        }
+        return true;
+    }
+    void set(const std::string& key, const std::string& value) { (*values_)[strip(key)] = value; }
+    template <typename T> bool getParam(const std::string& key, T& out) const {
+        auto it = values_->find(strip(key));
+        if (it == values_->end()) return false;
+        std::istringstream ss(it->second);
+        ss >> out;
+        return !ss.fail();
+    }
+    bool getParam(const std::string& key, std::string& out) const {
+        auto it = values_->find(strip(key));
+        if (it == values_->end()) return false;
+        out = it->second;
+        return true;
+    }
+    template <typename T> bool param(const std::string& key, T& out, const T& def) const {
+        if (getParam(key, out)) return true;
+        out = def;
+        return false;
+    }
+private:
+    static std::string strip(const std::string& k) { return !k.empty() && k[0] == '/' ? k.substr(1) : k; }
+    std::shared_ptr<std::map<std::string, std::string>> values_;
+};
+}  // namespace ros
+#endif
+
+namespace orbx_compat {
+static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint layout");
+static_assert(sizeof(cv::DMatch) == sizeof(orbx_match), "cv::DMatch layout");
+inline void check(orbx_status s, const char* where) {
+    if (s != ORBX_OK)
+        throw std::runtime_error(std::string(where) + ": " + orbx_status_string(s) + " " + orbx_last_error());
+}
+}  // namespace orbx_compat

@@ -1,0 +1,20 @@
+"""Sharding of independent units (frames, frame pairs) over ranks: contiguous blocks, results concatenated in
+unit order, no collective on the per-frame path.  The one exchange step of the path - replicating a key-frame
+descriptor set for many-to-many matching - is an all-gather of uint8 rows."""
+
+
+def shard_range(n_units, rank, world):
+    """Units [lo, hi) owned by `rank`: block i*n/world .. (i+1)*n/world."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    return (rank * n_units) // world, ((rank + 1) * n_units) // world
+
+
+def all_gather_descriptors(local_desc, dist):
+    """Replicates per-rank descriptor blocks ([k_local, n, 32] uint8 torch tensors of equal shape) on every rank
+    (RCCL all-gather on GPUs, gloo on CPU).  Returns [world * k_local, n, 32]."""
+    import torch
+    world = dist.get_world_size()
+    out = [torch.empty_like(local_desc) for _ in range(world)]
+    dist.all_gather(out, local_desc.contiguous())
+    return torch.cat(out, 0)

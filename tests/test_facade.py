@@ -1,0 +1,35 @@
+"""The drop-in C++ headers (include/orb_slam/...) compile against the C ABI without OpenCV/ROS, read the
+reference's parameter files, and (GPU) run extract -> match -> F/H through the facade classes."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "facade_check")
+
+
+def _build():
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-std=c++17", "-DORBX_NO_OPENCV", "-DORBX_NO_ROS", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "facade_check.cpp"), "-o", EXE, "-L" + os.path.join(ROOT, "orb_slam_amd"),
+           "-lorbx", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "orb_slam_amd"), "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    subprocess.check_call(cmd)
+
+
+def test_facade_compiles_and_reads_reference_yaml():
+    _build()
+    out = subprocess.check_output([EXE, "norun", os.path.join(ROOT, "tests", "golden", "cfg")], text=True)
+    assert "n_key_points=1000" in out
+
+
+@pytest.mark.gpu
+def test_facade_runs_on_gpu():
+    if not os.path.exists(EXE):
+        _build()
+    out = subprocess.check_output([EXE, "run", os.path.join(ROOT, "tests", "golden", "cfg")], text=True, timeout=120)
+    assert "levels=8" in out and "H empty=0" in out
+    kp = int(out.split("kp=")[1].split()[0])
+    assert kp > 300 and f"desc={kp}" in out and f"matches=" in out
+    assert "sf1=1.20000005" in out
