@@ -36,12 +36,15 @@ struct orbx_extractor {
     int cur_w = -1, cur_h = -1, cur_levels = -1;
     Geom geom;
     std::vector<Tile> tiles;
+    std::vector<Strip> strips;
     std::vector<Coef> coefs;
     DevBuf<Tile> d_tiles;
+    DevBuf<Strip> d_strips;
     DevBuf<Coef> d_coefs;
     DevBuf<BriefPattern> d_pattern;
     UMax umax;
     BlurKernel blur_kernel;
+    BlurTaps blur_taps;
     float harris_scale_sq_sq = 0.f;
 
     size_t atlas_bytes = 0;
@@ -135,6 +138,7 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
 
     // mask words, tiles, resize coefficients
     h->tiles.clear();
+    h->strips.clear();
     h->coefs.clear();
     int words = 0;
     for (int level = 0; level < nlevels; level++) {
@@ -144,6 +148,9 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
         words += L.words_per_row * L.h;
         for (int y0 = 0; y0 < L.h; y0 += kTileH)
             for (int x0 = 0; x0 < L.w; x0 += kTileW) h->tiles.push_back(Tile{(int16_t)level, 0, (int16_t)x0, (int16_t)y0});
+        for (int y0 = 0; y0 < L.h; y0 += 2 * kStripRows)
+            for (int ax0 = L.x & ~3; ax0 < L.x + L.w; ax0 += 128)
+                h->strips.push_back(Strip{(int16_t)level, 0, (int16_t)ax0, (int16_t)y0});
         if (level > 0) {
             // cv::resize INTER_LINEAR_EXACT, interpolationLinear<uchar>::getCoeffs: Q8 weights from IEEE double
             const LevelInfo& S = g.L[level - 1];
@@ -179,6 +186,8 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
     g.total_tiles = (int)h->tiles.size();
     h->atlas_bytes = (size_t)g.atlas_w * g.atlas_h;
     ORBX_TRY(h->d_tiles.ensure(h->tiles.size()));
+    ORBX_TRY(h->d_strips.ensure(h->strips.size()));
+    ORBX_HIP(hipMemcpyAsync(h->d_strips.p, h->strips.data(), h->strips.size() * sizeof(Strip), hipMemcpyHostToDevice, h->stream));
     ORBX_TRY(h->d_coefs.ensure(std::max<size_t>(h->coefs.size(), 1)));
     ORBX_HIP(hipMemcpyAsync(h->d_tiles.p, h->tiles.data(), h->tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, h->stream));
     if (!h->coefs.empty())
@@ -287,8 +296,8 @@ orbx_status run_describe_stage(orbx_extractor* h, int frames) {
     hipStream_t s = h->stream;
     size_t A = h->atlas_bytes;
     h->timer.begin(ST_BLUR, s);
-    hipLaunchKernelGGL(k_blur, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A, g,
-                       h->d_tiles.p, h->blur_kernel);
+    hipLaunchKernelGGL(k_blur, dim3(div_up((int)h->strips.size(), 4), frames), dim3(256), 0, s, h->d_atlas.p,
+                       h->d_blur.p, A, g, h->d_strips.p, (int)h->strips.size(), h->blur_taps);
     h->timer.end(ST_BLUR, s);
     h->timer.begin(ST_BRIEF, s);
     hipLaunchKernelGGL(k_brief, dim3(div_up(h->kp_cap, 8), frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A, g,
@@ -418,6 +427,12 @@ orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_w
             cf[i] = (float)(cf[i] * sum);
             h->blur_kernel.k[i] = (int)lrintf(cf[i] * 256.f);
         }
+        const int* k = h->blur_kernel.k;
+        // the kernel packs the taps for v_dot4_u32_u8: they must be symmetric bytes
+        if (k[0] != k[6] || k[1] != k[5] || k[2] != k[4] || k[3] > 255 || k[0] < 0) { orbx_extractor_destroy(h); return ORBX_UNSUPPORTED; }
+        h->blur_taps.wa = (unsigned)k[0] | ((unsigned)k[1] << 8) | ((unsigned)k[2] << 16) | ((unsigned)k[3] << 24);
+        h->blur_taps.wb = (unsigned)k[2] | ((unsigned)k[1] << 8) | ((unsigned)k[0] << 16);
+        for (int i = 0; i < 4; i++) h->blur_taps.k[i] = k[i];
     }
     {
         float scale = 1.f / ((1 << 2) * 7 * 255.f);
@@ -437,7 +452,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    h->d_tiles.release(); h->d_coefs.release(); h->d_pattern.release();
+    h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_pattern.release();
     h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
     h->d_mask.release(); h->d_cand.release(); h->d_packed.release();
     h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();

@@ -359,45 +359,56 @@ __global__ void k_pack_cands(const Cand* __restrict__ cand, int cap, const int* 
 struct BlurKernel { int k[7]; };
 
 // K7: cv::GaussianBlur(7x7, sigma 2) of every level as cv::ORB applies it (8-bit fixed-point separable filter,
-// taps round(g*256), rows then columns, (sum + 2^15) >> 16).  Reads the un-blurred atlas including the level's
-// border, writes level interiors only.
+// taps round(g*256), rows then columns, (sum + 2^15) >> 16).  Dword-wise: a lane owns 4 adjacent atlas pixels of a
+// 32-row column strip.  Per input row it loads the three aligned dwords around them, forms the four horizontal sums
+// with v_alignbyte + v_dot4_u32_u8 (they fit 16 bits: the taps sum to 257), keeps the last seven rows of sums in
+// registers and emits one packed output dword per row.  No LDS; the halo rows/columns come from the atlas border.
+// Reads the un-blurred atlas, writes level interiors (plus at most 3 bytes of never-read border per row end).
+struct BlurTaps { unsigned wa, wb; int k[4]; };
+
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ blurred,
-                                              size_t atlas_bytes, Geom g, const Tile* __restrict__ tiles,
-                                              BlurKernel bk) {
-    __shared__ uint8_t src[kTileH + 6][kTileW + 8];
-    __shared__ int hrow[kTileH + 6][kTileW];
-    const Tile tl = tiles[blockIdx.x];
-    const LevelInfo L = g.L[tl.level];
-    const int b = blockIdx.y;
+                                              size_t atlas_bytes, Geom g, const Strip* __restrict__ strips,
+                                              int n_strips, BlurTaps bt) {
+    const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sidx >= n_strips) return;
+    const Strip st = strips[sidx];
+    const LevelInfo L = g.L[st.level];
+    const int lane = threadIdx.x & 63;
+    const int ax = st.ax0 + (lane & 31) * 4;                 // atlas x of this lane's 4 pixels
+    const int y0 = st.y0 + (lane >> 5) * kStripRows;         // first level row of this half
+    if (ax + 3 < L.x || ax >= L.x + L.w || y0 >= L.h) return;
+    const int rows = min(kStripRows, L.h - y0);
     const int aw = g.atlas_w;
-    const uint8_t* base = atlas + (size_t)b * atlas_bytes;
-    const int ax0 = L.x + tl.x0 - 3, ay0 = L.y + tl.y0 - 3;
-    for (int i = threadIdx.x; i < (kTileH + 6) * (kTileW + 6); i += 256) {
-        int r = i / (kTileW + 6), c = i - r * (kTileW + 6);
-        int ax = min(max(ax0 + c, 0), aw - 1), ay = min(max(ay0 + r, 0), g.atlas_h - 1);
-        src[r][c] = base[(size_t)ay * aw + ax];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (kTileH + 6) * kTileW; i += 256) {
-        int r = i >> 6, c = i & 63;
-        int acc = 0;
+    const size_t fo = (size_t)blockIdx.y * atlas_bytes;
+    const uint8_t* src = atlas + fo + (size_t)(L.y + y0 - 3) * aw + ax;
+    uint8_t* dst = blurred + fo + (size_t)(L.y + y0) * aw + ax;
+    unsigned h[7][4];
 #pragma unroll
-        for (int k = 0; k < 7; k++) acc += bk.k[k] * src[r][c + k];
-        hrow[r][c] = acc;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 63;
-    const int x = tl.x0 + lx;
+    for (int r = 0; r < kStripRows + 6; r++) {
+        if (r < rows + 6) {
+            const unsigned* p = (const unsigned*)(src + (size_t)r * aw);
+            const unsigned lft = p[-1], c = p[0], rgt = p[1];
+            unsigned* hr = h[r % 7];
+            hr[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 1), bt.wa,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 1), bt.wb, 0u, false), false);
+            hr[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 2), bt.wa,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 2), bt.wb, 0u, false), false);
+            hr[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 3), bt.wa,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 3), bt.wb, 0u, false), false);
+            hr[3] = __builtin_amdgcn_udot4(c, bt.wa, __builtin_amdgcn_udot4(rgt, bt.wb, 0u, false), false);
+        }
+        if (r >= 6 && r - 6 < rows) {
+            unsigned out = 0;
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int ly = (threadIdx.x >> 6) + rr * 4;
-        const int y = tl.y0 + ly;
-        if (x >= L.w || y >= L.h) continue;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) acc += bk.k[k] * hrow[ly + k][lx];
-        int v = (acc + (1 << 15)) >> 16;
-        blurred[(size_t)b * atlas_bytes + (size_t)(L.y + y) * aw + L.x + x] = (uint8_t)min(max(v, 0), 255);
+            for (int j = 0; j < 4; j++) {
+                // rows r-6 .. r hold taps 0 .. 6 (symmetric): k3*h3 + k2*(h2+h4) + k1*(h1+h5) + k0*(h0+h6)
+                const unsigned v = bt.k[3] * h[(r - 3) % 7][j] + bt.k[2] * (h[(r - 4) % 7][j] + h[(r - 2) % 7][j]) +
+                                   bt.k[1] * (h[(r - 5) % 7][j] + h[(r - 1) % 7][j]) +
+                                   bt.k[0] * (h[(r - 6) % 7][j] + h[r % 7][j]);
+                out |= min((v + (1u << 15)) >> 16, 255u) << (8 * j);
+            }
+            *(unsigned*)(dst + (size_t)(r - 6) * aw) = out;
+        }
     }
 }
 

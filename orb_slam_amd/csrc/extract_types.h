@@ -45,6 +45,15 @@ struct Coef {
     int16_t w1;
 };
 
+// A strip of the dword-wise kernels: 128 atlas pixels (32 lanes x 4 bytes, 4-byte aligned in the atlas) by
+// 2 x kStripRows level rows (the two 32-lane halves of a wavefront take one half each).
+constexpr int kStripRows = 32;
+struct Strip {
+    int16_t level, pad;
+    int16_t ax0;   // atlas x of the strip's first pixel (multiple of 4)
+    int16_t y0;    // first level row
+};
+
 struct Tile {
     int16_t level, pad;
     int16_t x0, y0;

@@ -166,6 +166,10 @@ struct ProjArgs {
     int32_t* pushes;            // scratch [pairs][2 * pair_stride]: (bin, feature) of every histogram push
     int32_t* status;            // out [pairs]: 1 = a window held more than kListCap candidates
     int32_t* n_matches;         // out [pairs] or NULL
+    // pre-gathered search windows (K10a), or NULL: the resolve kernel gathers by itself
+    int32_t* win_n;             // [pairs][pair_stride]
+    int2* win_list;             // [pairs][pair_stride][kWinK] (feature index, Hamming distance)
+    int32_t* win_overflow;      // [pairs]
 };
 
 __device__ __forceinline__ int hamming32(const uint8_t* a, const uint8_t* b) {
@@ -181,6 +185,149 @@ __device__ __forceinline__ int hamming32(const uint8_t* a, const uint8_t* b) {
 // gather the search window from the CSR bucket grid in the reference's cell-scan order (x-major cells, features in
 // index order inside a cell), compute the Hamming distances in parallel, and lane 0 resolves the ordered list.
 // MODE 0 = frame-to-frame (orb_matcher.cpp:115-255), MODE 1 = map points (orb_matcher.cpp:257-352).
+constexpr int kWinK = 64;  // entries per reference point in the pre-gathered window lists
+
+struct Window {
+    float px, py, radius_scaled;
+    int min_level, max_level, left, up, ncy, ncells;
+    bool min_only;
+};
+
+// Points A's per-frame / per-pair views at pair `pair`.
+__device__ __forceinline__ void resolve_views(ProjArgs& A, int pair) {
+    const int fi = A.frame_index ? A.frame_index[pair] : 0;
+    const int ri = A.ref_index ? A.ref_index[pair] : 0;
+    A.n = A.counts ? A.counts[fi] : A.n;
+    A.n_ref = A.counts ? A.counts[ri] : A.n_ref;
+    A.kps += (size_t)fi * A.kp_stride;
+    A.desc += (size_t)fi * A.kp_stride * 32;
+    A.cell_start += (size_t)fi * A.cell_stride;
+    A.cell_items += (size_t)fi * A.kp_stride;
+    if (A.ref_kps) A.ref_kps += (size_t)ri * A.kp_stride;
+    A.ref_desc += (size_t)ri * A.kp_stride * 32;
+    const size_t po = (size_t)pair * A.pair_stride;
+    if (A.ref_flag) A.ref_flag += po;
+    A.proj_xy += po * 2;
+    if (A.proj_z) A.proj_z += po;
+    if (A.pred_level) A.pred_level += po;
+    if (A.view_cos) A.view_cos += po;
+    A.matched += po;
+    A.dists += po;
+    A.pushes += po * 2;
+    A.status += pair;
+    if (A.n_matches) A.n_matches += pair;
+    if (A.win_n) {
+        A.win_n += po;
+        A.win_list += po * kWinK;
+        A.win_overflow += pair;
+    }
+    A.n = min(A.n, kMaxFeatures);
+}
+
+// The per-reference-point tests and the search window (orb_matcher.cpp:146-209 / 268-303, frame.cpp:89-118).
+template <int MODE>
+__device__ __forceinline__ bool window_of(const ProjArgs& A, int ref_idx, Window& W) {
+    const orbx_grid& g = A.g;
+    if (A.ref_flag && !A.ref_flag[ref_idx]) return false;
+    W.px = A.proj_xy[2 * ref_idx];
+    W.py = A.proj_xy[2 * ref_idx + 1];
+    W.min_only = false;
+    int level;
+    if (MODE == 0) {
+        if (A.proj_z && A.proj_z[ref_idx] < 0) return false;
+        if (!(W.px > g.min_x && W.px < g.max_x && W.py > g.min_y && W.py < g.max_y)) return false;
+        level = A.ref_kps[ref_idx].octave;
+        if (level < 0 || level >= A.n_levels) return false;
+        W.radius_scaled = A.radius * A.scale_factors[level];
+        if (A.level_mode == 1) { W.min_level = level; W.max_level = 0x7fffffff; W.min_only = true; }
+        else if (A.level_mode == 2) { W.min_level = 0; W.max_level = level; }
+        else { W.min_level = level - 1; W.max_level = level + 1; }
+    } else {
+        level = A.pred_level[ref_idx];
+        if (level < 0 || level >= A.n_levels) return false;
+        const float by_cos = A.view_cos[ref_idx] > 0.998 ? 2.5f : 4.0f;
+        W.radius_scaled = A.radius * by_cos * A.scale_factors[level];
+        W.min_level = level - 1;
+        W.max_level = level;
+    }
+    W.left = max(0, (int)floorf(W.px - g.min_x - W.radius_scaled) / g.grid_size_x);
+    if (W.left >= g.grid_cols) return false;
+    const int right = min(g.grid_cols - 1, (int)ceilf(W.px - g.min_x + W.radius_scaled) / g.grid_size_x);
+    if (right < 0) return false;
+    W.up = max(0, (int)floorf(W.py - g.min_y - W.radius_scaled) / g.grid_size_y);
+    if (W.up >= g.grid_rows) return false;
+    const int down = min(g.grid_rows - 1, (int)ceilf(W.py - g.min_y + W.radius_scaled) / g.grid_size_y);
+    if (down < 0) return false;
+    W.ncy = down - W.up + 1;
+    W.ncells = (right - W.left + 1) * W.ncy;
+    return true;
+}
+
+// Feature test of Frame::getFeaturesAroundPoint: 4-argument overload (frame.cpp:151-183, compares with the CELL
+// index as the reference does) when min_only, 5-argument overload (frame.cpp:185-218) otherwise.
+__device__ __forceinline__ bool in_window(const orbx_keypoint& k, const Window& W, int cxi, int cyi) {
+    if (W.min_only) {
+        if (k.octave < W.min_level) return false;
+        return fabsf(k.x - (float)cxi) < W.radius_scaled && fabsf(k.y - (float)cyi) < W.radius_scaled;
+    }
+    if (k.octave < W.min_level || k.octave > W.max_level) return false;
+    return fabsf(k.x - W.px) < W.radius_scaled && fabsf(k.y - W.py) < W.radius_scaled;
+}
+
+// K10a: window gather, fully parallel: one wavefront per reference point collects every feature of its search
+// window in the reference's scan order (x-major cells, index order inside a cell) with its Hamming distance.
+// The "already matched" rule is NOT applied here (it is sequential); K10b applies it while resolving.
+// win_n[ref] = -1: point skipped; > kWinK: list too long, K10b gathers that point's window itself.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_window_gather(ProjArgs A) {
+    const int lane = threadIdx.x & 63;
+    resolve_views(A, blockIdx.y);
+    const int ref_idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ref_idx >= A.n_ref) return;
+    const orbx_grid& g = A.g;
+    Window W;
+    if (!window_of<MODE>(A, ref_idx, W)) {
+        if (lane == 0) A.win_n[ref_idx] = -1;
+        return;
+    }
+    const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
+    int2* list = A.win_list + (size_t)ref_idx * kWinK;
+    int list_n = 0;
+    for (int cbase = 0; cbase < W.ncells; cbase += 64) {
+        const int c = cbase + lane;
+        int cnt = 0, i0 = 0, i1 = 0, cxi = 0, cyi = 0;
+        if (c < W.ncells) {
+            cxi = W.left + c / W.ncy;
+            cyi = W.up + c % W.ncy;
+            const int cell = cxi * g.grid_rows + cyi;
+            i0 = A.cell_start[cell];
+            i1 = A.cell_start[cell + 1];
+        }
+        for (int i = i0; i < i1; i++) cnt += in_window(A.kps[A.cell_items[i]], W, cxi, cyi) ? 1 : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        int pos = list_n + incl - cnt;
+        list_n += total;
+        if (list_n > kWinK) break;
+        for (int i = i0; i < i1; i++) {
+            const int idx = A.cell_items[i];
+            if (in_window(A.kps[idx], W, cxi, cyi)) list[pos++] = make_int2(idx, hamming32(rd, A.desc + (size_t)idx * 32));
+        }
+    }
+    if (lane == 0) A.win_n[ref_idx] = list_n;
+}
+
+// K10b: projection matchers, one wavefront per frame pair.  Reference points are visited in order (the greedy
+// "already matched" rule of orb_matcher.cpp:216,313 makes the outer loop sequential).  With pre-gathered window
+// lists (K10a) each step is one coalesced list load (prefetched one point ahead), a flag lookup in LDS and a
+// wave reduction; without them (single-pair entry points, or a window longer than kWinK) the 64 lanes gather the
+// window from the CSR grid themselves.  MODE 0 = frame-to-frame (orb_matcher.cpp:115-255), MODE 1 = map points
+// (orb_matcher.cpp:257-352).
 template <int MODE>
 __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     extern __shared__ int32_t s_matched[];  // [n]
@@ -189,32 +336,7 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     __shared__ int32_t s_hist[30];
     const int lane = threadIdx.x;
     const orbx_grid g = A.g;
-    {
-        // resolve this pair's views
-        const int pair = blockIdx.x;
-        const int fi = A.frame_index ? A.frame_index[pair] : 0;
-        const int ri = A.ref_index ? A.ref_index[pair] : 0;
-        A.n = A.counts ? A.counts[fi] : A.n;
-        A.n_ref = A.counts ? A.counts[ri] : A.n_ref;
-        A.kps += (size_t)fi * A.kp_stride;
-        A.desc += (size_t)fi * A.kp_stride * 32;
-        A.cell_start += (size_t)fi * A.cell_stride;
-        A.cell_items += (size_t)fi * A.kp_stride;
-        if (A.ref_kps) A.ref_kps += (size_t)ri * A.kp_stride;
-        A.ref_desc += (size_t)ri * A.kp_stride * 32;
-        const size_t po = (size_t)pair * A.pair_stride;
-        if (A.ref_flag) A.ref_flag += po;
-        A.proj_xy += po * 2;
-        if (A.proj_z) A.proj_z += po;
-        if (A.pred_level) A.pred_level += po;
-        if (A.view_cos) A.view_cos += po;
-        A.matched += po;
-        A.dists += po;
-        A.pushes += po * 2;
-        A.status += pair;
-        if (A.n_matches) A.n_matches += pair;
-        A.n = min(A.n, kMaxFeatures);
-    }
+    resolve_views(A, blockIdx.x);
     {
         // flags cover the whole frame slot in the batched form: a stale grid entry (the reference's compute() may
         // erase keypoints after the grid was built) then reads "unmatched", never uninitialised memory
@@ -228,90 +350,113 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     __syncthreads();
     int n_push = 0;
     const float factor = 1.0f / 30;
+    const bool use_lists = A.win_n != nullptr;
+    // software prefetch of the next reference point's list entry for this lane
+    int next_n = -1;
+    int2 next_e = make_int2(-1, 0);
+    if (use_lists && A.n_ref > 0) {
+        next_n = A.win_n[0];
+        if (lane < next_n && next_n <= kWinK) next_e = A.win_list[lane];
+    }
     for (int ref_idx = 0; ref_idx < A.n_ref; ++ref_idx) {
-        if (A.ref_flag && !A.ref_flag[ref_idx]) continue;
-        const float px = A.proj_xy[2 * ref_idx], py = A.proj_xy[2 * ref_idx + 1];
-        int level, min_level, max_level;
-        bool min_only = false;
-        float radius_scaled;
-        if (MODE == 0) {
-            if (A.proj_z && A.proj_z[ref_idx] < 0) continue;
-            if (!(px > g.min_x && px < g.max_x && py > g.min_y && py < g.max_y)) continue;
-            level = A.ref_kps[ref_idx].octave;
-            if (level < 0 || level >= A.n_levels) continue;
-            radius_scaled = A.radius * A.scale_factors[level];
-            if (A.level_mode == 1) { min_level = level; max_level = 0x7fffffff; min_only = true; }
-            else if (A.level_mode == 2) { min_level = 0; max_level = level; }
-            else { min_level = level - 1; max_level = level + 1; }
-        } else {
-            level = A.pred_level[ref_idx];
-            if (level < 0 || level >= A.n_levels) continue;
-            const float by_cos = A.view_cos[ref_idx] > 0.998 ? 2.5f : 4.0f;
-            radius_scaled = A.radius * by_cos * A.scale_factors[level];
-            min_level = level - 1;
-            max_level = level;
-        }
-        // Frame::getBoxAroundPoint (frame.cpp:89-118)
-        const int left = max(0, (int)floorf(px - g.min_x - radius_scaled) / g.grid_size_x);
-        if (left >= g.grid_cols) continue;
-        const int right = min(g.grid_cols - 1, (int)ceilf(px - g.min_x + radius_scaled) / g.grid_size_x);
-        if (right < 0) continue;
-        const int up = max(0, (int)floorf(py - g.min_y - radius_scaled) / g.grid_size_y);
-        if (up >= g.grid_rows) continue;
-        const int down = min(g.grid_rows - 1, (int)ceilf(py - g.min_y + radius_scaled) / g.grid_size_y);
-        if (down < 0) continue;
-        const int ncy = down - up + 1;
-        const int ncells = (right - left + 1) * ncy;
-        // ordered gather of the window
         int list_n = 0;
-        bool overflow = false;
-        for (int cbase = 0; cbase < ncells; cbase += 64) {
-            const int c = cbase + lane;
-            int cnt = 0, i0 = 0, i1 = 0, cxi = 0, cyi = 0;
-            if (c < ncells) {
-                cxi = left + c / ncy;
-                cyi = up + c % ncy;
-                const int cell = cxi * g.grid_rows + cyi;
-                i0 = A.cell_start[cell];
-                i1 = A.cell_start[cell + 1];
+        int cur_n = 0;
+        int2 cur_e = make_int2(-1, 0);
+        if (use_lists) {
+            cur_n = next_n;
+            cur_e = next_e;
+            if (ref_idx + 1 < A.n_ref) {
+                next_n = A.win_n[ref_idx + 1];
+                next_e = make_int2(-1, 0);
+                if (lane < next_n && next_n <= kWinK) next_e = A.win_list[(size_t)(ref_idx + 1) * kWinK + lane];
             }
-            auto accept = [&](int idx) -> bool {
-                if (s_matched[idx] > 0) return false;
-                const orbx_keypoint k = A.kps[idx];
-                if (min_only) {
-                    // 4-argument overload (frame.cpp:151-183): distance to the CELL index, as the reference does
-                    if (k.octave < min_level) return false;
-                    return fabsf(k.x - (float)cxi) < radius_scaled && fabsf(k.y - (float)cyi) < radius_scaled;
-                }
-                if (k.octave < min_level || k.octave > max_level) return false;
-                return fabsf(k.x - px) < radius_scaled && fabsf(k.y - py) < radius_scaled;
-            };
-            for (int i = i0; i < i1; i++) cnt += accept(A.cell_items[i]) ? 1 : 0;
-            int incl = cnt;
+            if (cur_n <= 0) continue;
+        }
+        // a window longer than kWinK (rare) is gathered again here, sequentially, for this point only
+        if (use_lists && cur_n <= kWinK) {
+            const bool valid = lane < cur_n && !(s_matched[cur_e.x] > 0);
+            if (MODE == 0) {
+                // min distance, last in scan order wins ties (`<=` in orb_matcher.cpp:222)
+                unsigned long long key = valid ? (((unsigned long long)(unsigned)cur_e.y << 32) | (unsigned)(63 - lane))
+                                               : ~0ull;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            const int total = __shfl(incl, 63);
-            int pos = list_n + incl - cnt;
-            if (list_n + total > kListCap) overflow = true;
-            else
-                for (int i = i0; i < i1; i++) {
-                    const int idx = A.cell_items[i];
-                    if (accept(idx)) s_idx[pos++] = idx;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(key, o);
+                    key = other < key ? other : key;
                 }
-            if (overflow) break;
-            list_n += total;
+                if (key == ~0ull) continue;
+                const int min_d = (int)(key >> 32);
+                const int wl = 63 - (int)(key & 0xffffffffu);
+                const int id = __shfl(cur_e.x, wl);
+                if (min_d <= 100) {
+                    if (lane == 0) {
+                        s_matched[id] = ref_idx;
+                        A.dists[id] = min_d;
+                        if (A.check_orientation) {  // the rotation bin is computed after the loop
+                            A.pushes[2 * n_push] = ref_idx;
+                            A.pushes[2 * n_push + 1] = id;
+                            n_push++;
+                        }
+                    }
+                    __syncthreads();
+                }
+                continue;
+            }
+            // MODE 1: compact the still-free entries in order, then lane 0 walks them (below)
+            const unsigned long long bal = __ballot(valid);
+            if (valid) {
+                const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+                s_idx[pos] = cur_e.x;
+                s_dist[pos] = cur_e.y;
+            }
+            list_n = __popcll(bal);
+            __syncthreads();
+        } else {
+            Window W;
+            if (!window_of<MODE>(A, ref_idx, W)) continue;
+            // ordered gather of the window
+            bool overflow = false;
+            for (int cbase = 0; cbase < W.ncells; cbase += 64) {
+                const int c = cbase + lane;
+                int cnt = 0, i0 = 0, i1 = 0, cxi = 0, cyi = 0;
+                if (c < W.ncells) {
+                    cxi = W.left + c / W.ncy;
+                    cyi = W.up + c % W.ncy;
+                    const int cell = cxi * g.grid_rows + cyi;
+                    i0 = A.cell_start[cell];
+                    i1 = A.cell_start[cell + 1];
+                }
+                auto accept = [&](int idx) -> bool {
+                    if (s_matched[idx] > 0) return false;
+                    return in_window(A.kps[idx], W, cxi, cyi);
+                };
+                for (int i = i0; i < i1; i++) cnt += accept(A.cell_items[i]) ? 1 : 0;
+                int incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    int v = __shfl_up(incl, o);
+                    if (lane >= o) incl += v;
+                }
+                const int total = __shfl(incl, 63);
+                int pos = list_n + incl - cnt;
+                if (list_n + total > kListCap) overflow = true;
+                else
+                    for (int i = i0; i < i1; i++) {
+                        const int idx = A.cell_items[i];
+                        if (accept(idx)) s_idx[pos++] = idx;
+                    }
+                if (overflow) break;
+                list_n += total;
+            }
+            if (overflow) {
+                if (lane == 0) *A.status = 1;
+                break;
+            }
+            __syncthreads();
+            const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
+            for (int i = lane; i < list_n; i += 64) s_dist[i] = hamming32(rd, A.desc + (size_t)s_idx[i] * 32);
+            __syncthreads();
         }
-        if (overflow) {
-            if (lane == 0) *A.status = 1;
-            break;
-        }
-        __syncthreads();
-        const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
-        for (int i = lane; i < list_n; i += 64) s_dist[i] = hamming32(rd, A.desc + (size_t)s_idx[i] * 32);
-        __syncthreads();
         if (lane == 0 && list_n > 0) {
             if (MODE == 0) {
                 int min_d = 256, id = -1;
@@ -321,16 +466,9 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
                     s_matched[id] = ref_idx;
                     A.dists[id] = min_d;
                     if (A.check_orientation) {
-                        float rot = A.ref_kps[ref_idx].angle - A.kps[id].angle;
-                        if (rot < 0.0f) rot += 360.0f;
-                        int bin = (int)roundf(rot * factor);
-                        if (bin == 30) bin = 0;
-                        if (bin >= 0 && bin < 30) {
-                            s_hist[bin]++;
-                            A.pushes[2 * n_push] = bin;
-                            A.pushes[2 * n_push + 1] = id;
-                            n_push++;
-                        }
+                        A.pushes[2 * n_push] = ref_idx;
+                        A.pushes[2 * n_push + 1] = id;
+                        n_push++;
                     }
                 }
             } else {
@@ -355,6 +493,18 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     if (MODE == 0 && A.check_orientation) {
         // MatcherBase::applyRotationConstraint + computeThreeMaxima (orb_matcher.h:57-79, utils.cpp:202-236)
         n_push = __shfl(n_push, 0);
+        // rotation-difference bin of every accepted match (orb_matcher.cpp:231-243), deferred to here so that the
+        // sequential loop above never waits on the two angle loads
+        for (int i = lane; i < n_push; i += 64) {
+            float rot = A.ref_kps[A.pushes[2 * i]].angle - A.kps[A.pushes[2 * i + 1]].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin < 0 || bin >= 30) bin = -1;
+            else atomicAdd(&s_hist[bin], 1);
+            A.pushes[2 * i] = bin;
+        }
+        __syncthreads();
         int ind1 = -1, ind2 = -1, ind3 = -1;
         int max1 = 0, max2 = 0, max3 = 0;
         for (int i = 0; i < 30; i++) {
@@ -367,7 +517,7 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
         else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
         for (int i = lane; i < n_push; i += 64) {
             const int bin = A.pushes[2 * i];
-            if (bin != ind1 && bin != ind2 && bin != ind3) s_matched[A.pushes[2 * i + 1]] = 0;
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) s_matched[A.pushes[2 * i + 1]] = 0;
         }
         __syncthreads();
     }
@@ -392,6 +542,8 @@ struct orbx_matcher {
     DevBuf<int32_t> d_idx, d_dist, d_ints, d_cells, d_items, d_pushes;
     DevBuf<float> d_f0, d_f1, d_f2;
     DevBuf<orbx_keypoint> d_kp, d_refkp;
+    DevBuf<int32_t> d_win_n, d_win_over;
+    DevBuf<int2> d_win_list;
     std::vector<unsigned long long> h_best;
 };
 
@@ -431,6 +583,7 @@ void orbx_matcher_destroy(orbx_matcher* h) {
     h->d_q.release(); h->d_t.release(); h->d_flags.release(); h->d_best.release(); h->d_idx.release();
     h->d_dist.release(); h->d_ints.release(); h->d_cells.release(); h->d_items.release(); h->d_pushes.release();
     h->d_f0.release(); h->d_f1.release(); h->d_f2.release(); h->d_kp.release(); h->d_refkp.release();
+    h->d_win_n.release(); h->d_win_over.release(); h->d_win_list.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -615,9 +768,22 @@ static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g,
     A.pushes = h->d_pushes.p;
     A.status = d_status;
     A.n_matches = nullptr;
+    A.pair_stride = n_ref;  // one pair: strides only place the window lists
+    ORBX_TRY(h->d_win_n.ensure(n_ref));
+    ORBX_TRY(h->d_win_list.ensure((size_t)n_ref * kWinK));
+    ORBX_TRY(h->d_win_over.ensure(1));
+    ORBX_HIP(hipMemsetAsync(h->d_win_over.p, 0, sizeof(int32_t), s));
+    A.win_n = h->d_win_n.p;
+    A.win_list = h->d_win_list.p;
+    A.win_overflow = h->d_win_over.p;
     const size_t shmem = sizeof(int32_t) * (size_t)n;
-    if (mode == 0) hipLaunchKernelGGL(k_projection_match<0>, dim3(1), dim3(64), shmem, s, A);
-    else hipLaunchKernelGGL(k_projection_match<1>, dim3(1), dim3(64), shmem, s, A);
+    if (mode == 0) {
+        hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(n_ref, 4), 1), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_projection_match<0>, dim3(1), dim3(64), shmem, s, A);
+    } else {
+        hipLaunchKernelGGL(k_window_gather<1>, dim3(div_up(n_ref, 4), 1), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_projection_match<1>, dim3(1), dim3(64), shmem, s, A);
+    }
     ORBX_HIP(hipGetLastError());
     std::vector<int32_t> matched(n), dists(n);
     int32_t status = 0;
@@ -696,6 +862,14 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     A.pushes = h->d_pushes.p;
     A.status = h->d_ints.p;
     A.n_matches = d_n_matches;
+    ORBX_TRY(h->d_win_n.ensure((size_t)kp_capacity * n_pairs));
+    ORBX_TRY(h->d_win_list.ensure((size_t)kp_capacity * n_pairs * kWinK));
+    ORBX_TRY(h->d_win_over.ensure(n_pairs));
+    ORBX_HIP(hipMemsetAsync(h->d_win_over.p, 0, sizeof(int32_t) * n_pairs, s));
+    A.win_n = h->d_win_n.p;
+    A.win_list = h->d_win_list.p;
+    A.win_overflow = h->d_win_over.p;
+    hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 4), n_pairs), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_projection_match<0>, dim3(n_pairs), dim3(64), sizeof(int32_t) * (size_t)kp_capacity, s, A);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

@@ -307,3 +307,74 @@ def test_ransac_batch_equals_single(oracle, ransac):
         assert np.array_equal(d_if[p].cpu().numpy(), o["inliers_f"])
         assert np.array_equal(d_ih[p].cpu().numpy(), o["inliers_h"])
         assert d_sc[p, 0].item() == o["score_f"] and d_sc[p, 1].item() == o["score_h"]
+
+
+def test_frame_model_batch_and_batched_projection(oracle, test_images):
+    """orbx_extract_batch with the MonoFrame::extractFeatures frame model (undistort + grid + compute) and the
+    batched projection matcher on its device results, against the oracle run frame by frame."""
+    import torch
+    B, cap = 5, 1280
+    cam = orbx.make_camera(517.3, 516.5, 318.6, 255.3, [0.2624, -0.9531, -0.0054, 0.0026, 1.1633])
+    ocam = oracle.camera(517.3, 516.5, 318.6, 255.3, [0.2624, -0.9531, -0.0054, 0.0026, 1.1633], 640, 480)
+    bounds = oracle.image_bounds(ocam)
+    grid = orbx.make_grid(bounds)
+    og = oracle.grid_params(bounds)
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=B)
+    ex.set_frame_model(cam, grid)
+    mt = orbx.Matcher()
+    p = oracle.orb_params(nfeatures=1000)
+    rng = np.random.default_rng(31)
+    frames = [test_images[0], test_images[1], np.roll(test_images[0], 3, axis=1).copy(),
+              np.roll(test_images[1], -2, axis=0).copy(), test_images[0]]
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), B, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    ora = []
+    for f, img in enumerate(frames):
+        k = oracle.detect(p, img)
+        xy = oracle.undistort_points(ocam, np.stack([k["x"], k["y"]], 1))
+        k["x"], k["y"] = xy[:, 0], xy[:, 1]
+        k, start, items = oracle.assign_grid(og, k)
+        k2, d = oracle.compute(p, img, k)
+        assert counts[f] == len(k2)
+        assert np.array_equal(kps[f, :counts[f]], k2.astype(orbx.KP_DTYPE)) and np.array_equal(desc[f, :counts[f]], d)
+        assert np.array_equal(orbx.undistort_points(cam, np.stack([k["x"], k["y"]], 1)),
+                              oracle.undistort_points(ocam, np.stack([k["x"], k["y"]], 1)))
+        ora.append((k2, d, start, items))
+    _, sf, _, _, _ = ex.scale_tables()
+    pairs = [(1, 0), (2, 1), (3, 2), (4, 3), (0, 4), (4, 0)]
+    P = len(pairs)
+    proj = np.zeros((P, cap, 2), np.float32)
+    for i, (f, r) in enumerate(pairs):
+        rk = ora[r][0]
+        proj[i, :len(rk), 0] = rk["x"] + rng.normal(0, 3, len(rk)).astype(np.float32)
+        proj[i, :len(rk), 1] = rk["y"] + rng.normal(0, 3, len(rk)).astype(np.float32)
+    d_fi = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device="cuda")
+    d_ri = torch.tensor([b for _, b in pairs], dtype=torch.int32, device="cuda")
+    d_proj = torch.from_numpy(proj).cuda()
+    d_matched = torch.zeros((P, cap), dtype=torch.int32, device="cuda")
+    d_dist = torch.zeros((P, cap), dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    kp_ptr, desc_ptr, cnt_ptr, kcap = ex.device_results()
+    cs_ptr, ci_ptr = ex.device_grid()
+    assert kcap == cap
+    for radius, orient in ((15.0, True), (40.0, False)):
+        mt.match_projection_frame_batch(grid, P, d_fi.data_ptr(), d_ri.data_ptr(), kp_ptr, desc_ptr, cnt_ptr, cap,
+                                        cs_ptr, ci_ptr, 0, d_proj.data_ptr(), 0, sf, 0, radius, orient,
+                                        d_matched.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr())
+        torch.cuda.synchronize()
+        hm, hd, hn = d_matched.cpu().numpy(), d_dist.cpu().numpy(), d_nm.cpu().numpy()
+        for i, (f, r) in enumerate(pairs):
+            fk, fd, start, items = ora[f]
+            rk, rd = ora[r][0], ora[r][1]
+            om = oracle.match_projection_frame(og, start, items, fk, fd, rk, np.ones(len(rk), np.uint8),
+                                               proj[i, :len(rk)], np.ones(len(rk), np.float32), rd, sf, 0, radius,
+                                               orient)
+            got_q = np.nonzero(hm[i, :len(fk)] > 0)[0]
+            assert hn[i] == len(om) == len(got_q), (i, radius)
+            assert np.array_equal(got_q, om["query"]) and np.array_equal(hm[i, got_q], om["train"])
+            assert np.array_equal(hd[i, got_q].astype(np.float32), om["distance"])
+        assert hn.min() > 100
+    ex.close()
+    mt.close()
