@@ -106,6 +106,12 @@ typedef struct {
    Frame::assignFeaturesToGrid (grid != NULL), and described at the undistorted coordinates.  NULL clears. */
 orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera* camera, const orbx_grid* grid);
 
+/* orbx_extract_batch has two equivalent forms of the steps between the detect kernels and the describe kernels
+   (keypoint selection, undistortion, grid, border filter): on the device (default, nothing crosses PCIe) or on
+   the host with the reference's own std:: calls (enabled = 0).  Results are identical; the switch exists for
+   tests and for frames with more candidates than the device form holds on chip. */
+orbx_status orbx_extractor_set_device_select(orbx_extractor* h, int enabled);
+
 /* Camera::undistortPoints on n (x,y) float pairs; host arithmetic in double as cv::undistortPoints. */
 orbx_status orbx_undistort_points(const orbx_camera* camera, const float* xy_in, int n, float* xy_out);
 
@@ -126,7 +132,7 @@ orbx_status orbx_extractor_layout(const orbx_extractor* h, int width, int height
                                   int32_t* rects_xywh, float* layer_scales);
 orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, uint8_t* out, size_t out_bytes);
 /* Per-kernel launch durations (ms) of the last call, measured with HIP events on the handle's stream.
-   names: gray, resize, fast, nms, emit, harris, blur, brief.  Returns the number written (<= cap). */
+   names: gray, resize, fast, nms, emit, harris, blur, brief, select.  Returns the number written (<= cap). */
 int orbx_extractor_last_timings(const orbx_extractor* h, float* ms, int cap);
 
 /* ------------------------------------------------------------------ matching -------------------------------- */
@@ -241,6 +247,11 @@ orbx_status orbx_ransac_make_sets(int n, int iterations, uint32_t seed0, uint32_
 
 /* Per-kernel launch durations (ms) of the last batch call: normalize, solve, score_f, score_h, select. */
 int orbx_ransac_last_timings(const orbx_ransac* h, float* ms, int cap);
+
+/* Test hook (no counterpart in the reference): runs the library's own replay of cv::KeyPointsFilter::retainBest
+   (std::nth_element + std::partition, the order-defining step of cv::ORB::detect) on the host.  perm_out receives
+   the original indices of the kept responses in their final order. */
+orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, int32_t* perm_out, int* new_n);
 
 /* Sets the HIP stream (hipStream_t as void*) a handle launches on; NULL restores the handle's own stream. */
 orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream);

@@ -77,6 +77,7 @@ int  orc_orb_compute(const orc_orb_params* p, const uint8_t* img, int w, int h, 
 /* The reference's own scale tables (orb_extractor.h:39-54). out = 4 arrays of nlevels floats, log factor returned. */
 float orc_scale_tables(float scale_factor, int nlevels, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
 float orc_fast_atan2(float y, float x);
+int  orc_retain_best(const float* keys, int n, int n_points, int32_t* perm_out);
 
 /* ---- camera (adjacent) ---- */
 typedef struct { double fx, fy, cx, cy, k1, k2, p1, p2, k3; int32_t width, height; } orc_camera;

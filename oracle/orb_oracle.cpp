@@ -695,6 +695,16 @@ float orc_scale_tables(float scale_factor, int nlevels, float* scale, float* inv
 
 float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 
+/* cv::KeyPointsFilter::retainBest on bare responses (the real std::nth_element / std::partition): perm_out receives
+   the original indices in the order the kept keypoints end up in; returns the new length. */
+int orc_retain_best(const float* keys, int n, int n_points, int32_t* perm_out) {
+    std::vector<orc_keypoint> k(n);
+    for (int i = 0; i < n; i++) k[i] = orc_keypoint{0.f, 0.f, 0.f, 0.f, keys[i], 0, i};
+    retain_best(k, n_points, 0);
+    for (size_t i = 0; i < k.size(); i++) perm_out[i] = k[i].class_id;
+    return (int)k.size();
+}
+
 /* calib3d undistort.cpp cvUndistortPoints with P = K, 5 fixed-point iterations (camera.cpp:97-126). */
 void orc_undistort_points(const orc_camera* c, const float* xy_in, int n, float* xy_out) {
     double ifx = 1. / c->fx, ify = 1. / c->fy;

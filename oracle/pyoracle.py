@@ -158,6 +158,13 @@ def fast_atan2(y, x):
     return lib().orc_fast_atan2(y, x)
 
 
+def retain_best(keys, n_points):
+    keys = np.ascontiguousarray(keys, np.float32)
+    perm = np.zeros(max(len(keys), 1), np.int32)
+    n = lib().orc_retain_best(_p(keys), len(keys), n_points, _p(perm))
+    return perm[:n].copy()
+
+
 def camera(fx, fy, cx, cy, dist, width, height):
     f = lambda v: float(np.float32(v))  # the reference keeps intrinsics in cv::Mat_<float>
     return Camera(f(fx), f(fy), f(cx), f(cy), f(dist[0]), f(dist[1]), f(dist[2]), f(dist[3]), f(dist[4]),

@@ -18,7 +18,7 @@ const int kBitPattern31[256 * 4] = {
 #include "bit_pattern_31.inc"
 };
 
-enum Stage { ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_NMS, ST_EMIT, ST_HARRIS, ST_BLUR, ST_BRIEF, ST_COUNT };
+enum Stage { ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_NMS, ST_EMIT, ST_HARRIS, ST_BLUR, ST_BRIEF, ST_SELECT, ST_COUNT };
 
 inline int cv_round(double v) { return (int)lrint(v); }
 inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
@@ -66,6 +66,10 @@ struct orbx_extractor {
     orbx_grid grid;
     DevBuf<int32_t> d_cell_start, d_cell_items;
     PinBuf<int32_t> h_cell_start, h_cell_items;
+    DevBuf<int> d_status;
+    bool device_select = true;     // batch path: select / undistort / grid on the device (k_select_frame)
+    bool select_attr_set = false;
+    size_t select_attr_bytes = 0;
     int last_frames = 0;
     bool pyramid_valid = false;  // atlas holds the pyramid of the frames of the last detect stage
 
@@ -259,7 +263,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
                        h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
-    hipLaunchKernelGGL(k_harris_angle, dim3(div_up(h->cand_cap, 4), frames), dim3(256), 0, s, h->d_atlas.p, A, g,
+    hipLaunchKernelGGL(k_harris_angle, dim3(frames >= 64 ? 16 : 256, frames), dim3(256), 0, s, h->d_atlas.p, A, g,
                        h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq);
     T.end(ST_HARRIS, s);
     ORBX_HIP(hipGetLastError());
@@ -459,6 +463,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_kp_counts.release(); h->d_kp.release();
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();
     h->d_cell_start.release(); h->d_cell_items.release(); h->h_cell_start.release(); h->h_cell_items.release();
+    h->d_status.release();
     h->timer.destroy();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -594,6 +599,68 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(ensure_buffers(h, n_frames));
     h->last_frames = n_frames;
     ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels));
+
+    // Device-resident path: selection, undistortion, bucket grid and border filter run in one kernel per frame
+    // (k_select_frame), so nothing crosses PCIe between detect and compute.  It covers frames whose candidates fit
+    // its LDS; otherwise (status 2) the whole batch is redone by the host path below, which has no such limit.
+    const int ncell_dev = h->has_grid ? h->grid.grid_cols * h->grid.grid_rows : 0;
+    if (h->device_select && capacity <= 4096 && ncell_dev + 1 <= kSelectMaxCands * 2) {
+        h->kp_cap = capacity;
+        ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
+        ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
+        ORBX_TRY(h->d_kp_counts.ensure(n_frames));
+        ORBX_TRY(h->d_status.ensure(n_frames));
+        if (h->has_grid) {
+            ORBX_TRY(h->d_cell_start.ensure((size_t)(ncell_dev + 1) * n_frames));
+            ORBX_TRY(h->d_cell_items.ensure((size_t)capacity * n_frames));
+        }
+        FrameModel fm;
+        std::memset(&fm, 0, sizeof(fm));
+        fm.has_camera = h->has_camera;
+        fm.has_grid = h->has_grid;
+        if (h->has_camera) fm.cam = h->camera;
+        if (h->has_grid) fm.grid = h->grid;
+        fm.width = width;
+        fm.height = height;
+        fm.edge = h->prm.edge_threshold;
+        fm.patch_size = h->prm.patch_size;
+        const size_t shmem = sizeof(stdsel::Elem) * kSelectMaxCands + (size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int));
+        if (!h->select_attr_set || shmem > h->select_attr_bytes) {
+            ORBX_HIP(hipFuncSetAttribute((const void*)k_select_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            h->select_attr_set = true;
+            h->select_attr_bytes = shmem;
+        }
+        h->timer.begin(ST_SELECT, h->stream);
+        hipLaunchKernelGGL(k_select_frame, dim3(n_frames), dim3(64 * h->geom.nlevels), shmem, h->stream, h->d_cand.p,
+                           h->cand_cap, h->d_level_counts.p, h->d_totals.p, h->geom, fm, h->d_kp.p, capacity,
+                           h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p);
+        h->timer.end(ST_SELECT, h->stream);
+        ORBX_HIP(hipGetLastError());
+        ORBX_TRY(run_describe_stage(h, n_frames));
+        ORBX_TRY(h->h_ints.ensure((size_t)n_frames * (2 * kMaxLevels + 2) + 1));
+        int* h_status = h->h_ints.p;
+        int* h_cnt = h->h_ints.p + n_frames;
+        ORBX_HIP(hipMemcpyAsync(h_status, h->d_status.p, sizeof(int) * n_frames, hipMemcpyDeviceToHost, h->stream));
+        ORBX_HIP(hipMemcpyAsync(h_cnt, h->d_kp_counts.p, sizeof(int) * n_frames, hipMemcpyDeviceToHost, h->stream));
+        if (keypoints)
+            ORBX_HIP(hipMemcpyAsync(keypoints, h->d_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
+                                    hipMemcpyDeviceToHost, h->stream));
+        if (descriptors)
+            ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost,
+                                    h->stream));
+        ORBX_HIP(hipStreamSynchronize(h->stream));
+        collect_timings(h);
+        bool redo = false;
+        for (int f = 0; f < n_frames; f++) {
+            if (h_status[f] == 1) return ORBX_CAPACITY;
+            if (h_status[f] == 2) redo = true;
+        }
+        if (!redo) {
+            if (counts) std::memcpy(counts, h_cnt, sizeof(int) * n_frames);
+            return ORBX_OK;
+        }
+    }
+
     std::vector<std::vector<orbx_keypoint>> sel;
     ORBX_TRY(select_keypoints(h, n_frames, sel));
     // MonoFrame::extractFeatures between detect and compute (mono_frame.cpp:85-100): undistort, bucket, filter
@@ -680,6 +747,12 @@ orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera*
     h->has_grid = grid != nullptr;
     if (camera) h->camera = *camera;
     if (grid) h->grid = *grid;
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_set_device_select(orbx_extractor* h, int enabled) {
+    if (!h) return ORBX_BAD_ARG;
+    h->device_select = enabled != 0;
     return ORBX_OK;
 }
 

@@ -8,6 +8,7 @@
 
 #include "extract_types.h"
 #include "orbx.h"
+#include "stdsel.h"
 
 namespace orbx {
 
@@ -289,51 +290,258 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
                                                       Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
                                                       const int* __restrict__ thresholds, UMax umax,
                                                       float scale_sq_sq) {
-    const int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y;
-    if (idx >= cap || idx >= totals[b]) return;
-    Cand* cp = cand + (size_t)b * cap + idx;
-    const Cand c = *cp;
-    if ((int)c.score < thresholds[b * kMaxLevels + c.level]) return;
-    const LevelInfo L = g.L[c.level];
+    const int total = min(totals[b], cap);
     const int aw = g.atlas_w;
-    const uint8_t* center = atlas + (size_t)b * atlas_bytes + (size_t)(L.y + c.y) * aw + L.x + c.x;
-    int ha = 0, hb = 0, hc = 0;
-    if (lane < 49) {
-        const int i = lane / 7 - 3, j = lane - (lane / 7) * 7 - 3;
-        const uint8_t* p = center + i * aw + j;
-        const int Ix = (p[1] - p[-1]) * 2 + (p[-aw + 1] - p[-aw - 1]) + (p[aw + 1] - p[aw - 1]);
-        const int Iy = (p[aw] - p[-aw]) * 2 + (p[aw - 1] - p[-aw - 1]) + (p[aw + 1] - p[-aw + 1]);
-        ha = Ix * Ix;
-        hb = Iy * Iy;
-        hc = Ix * Iy;
-    }
-    ha = wave_sum_i32(ha);
-    hb = wave_sum_i32(hb);
-    hc = wave_sum_i32(hc);
-    int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        const int v = lane - 15;
-        const int d = umax.v[v < 0 ? -v : v];
-        const uint8_t* row = center + v * aw;
-        int s = 0, su = 0;
-        for (int u = -d; u <= d; u++) {
-            const int val = row[u];
-            s += val;
-            su += u * val;
+    // grid-stride over the frame's candidates: gridDim.x * 4 wavefronts per frame
+    for (int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 6); idx < total; idx += gridDim.x * 4) {
+        Cand* cp = cand + (size_t)b * cap + idx;
+        const Cand c = *cp;
+        if ((int)c.score < thresholds[b * kMaxLevels + c.level]) continue;
+        const LevelInfo L = g.L[c.level];
+        const uint8_t* center = atlas + (size_t)b * atlas_bytes + (size_t)(L.y + c.y) * aw + L.x + c.x;
+        int ha = 0, hb = 0, hc = 0;
+        if (lane < 49) {
+            const int i = lane / 7 - 3, j = lane - (lane / 7) * 7 - 3;
+            const uint8_t* p = center + i * aw + j;
+            const int Ix = (p[1] - p[-1]) * 2 + (p[-aw + 1] - p[-aw - 1]) + (p[aw + 1] - p[aw - 1]);
+            const int Iy = (p[aw] - p[-aw]) * 2 + (p[aw - 1] - p[-aw - 1]) + (p[aw + 1] - p[-aw + 1]);
+            ha = Ix * Ix;
+            hb = Iy * Iy;
+            hc = Ix * Iy;
         }
-        m10 = su;
-        m01 = v * s;
+        ha = wave_sum_i32(ha);
+        hb = wave_sum_i32(hb);
+        hc = wave_sum_i32(hc);
+        int m10 = 0, m01 = 0;
+        if (lane < 31) {
+            const int v = lane - 15;
+            const int d = umax.v[v < 0 ? -v : v];
+            const uint8_t* row = center + v * aw;
+            int s = 0, su = 0;
+            for (int u = -d; u <= d; u++) {
+                const int val = row[u];
+                s += val;
+                su += u * val;
+            }
+            m10 = su;
+            m01 = v * s;
+        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+        if (lane == 0) {
+            const float fa = (float)ha, fb = (float)hb, fc = (float)hc;
+            const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+            cp->harris = resp;
+            cp->angle = fast_atan2_deg((float)m01, (float)m10);
+        }
     }
-    m10 = wave_sum_i32(m10);
-    m01 = wave_sum_i32(m01);
-    if (lane == 0) {
-        const float fa = (float)ha, fb = (float)hb, fc = (float)hc;
-        const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
-        cp->harris = resp;
-        cp->angle = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// Frame model of MonoFrame::extractFeatures for the device-resident batch path.
+struct FrameModel {
+    int has_camera, has_grid;
+    orbx_camera cam;
+    orbx_grid grid;
+    int width, height, edge, patch_size;
+};
+
+constexpr int kSelectMaxCands = 8192;  // candidates of one frame the selection kernel holds in LDS
+
+__device__ __forceinline__ bool border_ok(const orbx_keypoint& k, int w, int h, int border) {
+    // cv::KeyPointsFilter::runByImageBorder: Rect(border, border, w - 2 border, h - 2 border).contains(round(pt))
+    if (border <= 0) return true;
+    if (h <= border * 2 || w <= border * 2) return false;
+    const int px = __float2int_rn(k.x), py = __float2int_rn(k.y);
+    return border <= px && px < w - border && border <= py && py < h - border;
+}
+
+// Ordered in-place compaction of s_kp[0..n) by one wavefront; keep() decides per keypoint.  Returns the new count
+// (valid on every lane).
+template <typename Keep>
+__device__ __forceinline__ int compact_ordered(orbx_keypoint* s_kp, int n, int lane, Keep keep) {
+    int running = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        orbx_keypoint k;
+        bool f = false;
+        if (i < n) {
+            k = s_kp[i];
+            f = keep(k);
+        }
+        const unsigned long long bal = __ballot(f);
+        if (f) s_kp[running + __popcll(bal & ((1ull << lane) - 1ull))] = k;
+        running += __popcll(bal);
     }
+    return running;
+}
+
+// Device half of cv::ORB::detect after the kernels above, plus the host steps MonoFrame::extractFeatures performs
+// between detect and compute - one workgroup per frame, one wavefront per pyramid level:
+//   retainBest(2*quota) on the FAST score, retainBest(quota) on the Harris response (lane 0 of the level's wave
+//   replays libstdc++'s nth_element + partition, stdsel.h), keypoint assembly (size, angle, level-0 coordinates),
+//   Camera::undistortPoints, Frame::assignFeaturesToGrid (ordered filter + CSR cells), and the border filter of
+//   cv::ORB::compute.  status[frame]: 0 ok, 1 more keypoints than kp_cap, 2 more candidates than the LDS holds.
+__global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ cand, int cand_cap,
+                                                        const int* __restrict__ level_counts,
+                                                        const int* __restrict__ totals, Geom g, FrameModel fm,
+                                                        orbx_keypoint* __restrict__ kps_out, int kp_cap,
+                                                        int* __restrict__ kp_counts, int* __restrict__ cell_start,
+                                                        int* __restrict__ cell_items, int* __restrict__ status) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ int s_n[kMaxLevels], s_off[kMaxLevels], s_cnt;
+    stdsel::Elem* s_el = (stdsel::Elem*)s_raw;                                  // [kSelectMaxCands]
+    orbx_keypoint* s_kp = (orbx_keypoint*)(s_raw + sizeof(stdsel::Elem) * kSelectMaxCands);  // [kp_cap]
+    int* s_cell = (int*)(s_kp + kp_cap);                                         // [kp_cap]
+    int* s_cells = (int*)s_raw;                                                  // [ncell + 1], aliases s_el later
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, lvl = tid >> 6;
+    const Cand* cd = cand + (size_t)b * cand_cap;
+    const int total = totals[b];
+    if (total > kSelectMaxCands || total > cand_cap) {
+        if (tid == 0) { status[b] = 2; kp_counts[b] = 0; }
+        return;
+    }
+    int n = 0, off = 0;
+    if (lvl < g.nlevels) {
+        n = level_counts[b * kMaxLevels + lvl];
+        for (int j = 0; j < lvl; j++) off += level_counts[b * kMaxLevels + j];
+        for (int i = lane; i < n; i += 64) s_el[off + i] = stdsel::Elem{(float)cd[off + i].score, off + i};
+    }
+    __syncthreads();
+    if (lvl < g.nlevels && lane == 0) n = stdsel::retain_best(s_el + off, n, 2 * g.L[lvl].quota);
+    n = __shfl(n, 0);
+    __syncthreads();
+    if (lvl < g.nlevels)
+        for (int i = lane; i < n; i += 64) s_el[off + i].key = cd[s_el[off + i].idx].harris;
+    __syncthreads();
+    if (lvl < g.nlevels && lane == 0) {
+        n = stdsel::retain_best(s_el + off, n, g.L[lvl].quota);
+        s_n[lvl] = n;
+    }
+    n = __shfl(n, 0);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int l = 0; l < g.nlevels; l++) { s_off[l] = acc; acc += s_n[l]; }
+        s_cnt = acc;
+    }
+    __syncthreads();
+    int count = s_cnt;
+    if (count > kp_cap) {
+        if (tid == 0) { status[b] = 1; kp_counts[b] = count; }
+        return;
+    }
+    if (lvl < g.nlevels) {
+        const float sf = g.L[lvl].scale;
+        const int oo = s_off[lvl];
+        for (int i = lane; i < n; i += 64) {
+            const Cand c = cd[s_el[off + i].idx];
+            orbx_keypoint k;
+            k.x = (float)c.x * sf;
+            k.y = (float)c.y * sf;
+            k.size = fm.patch_size * sf;
+            k.angle = c.angle;
+            k.response = c.harris;
+            k.octave = lvl;
+            k.class_id = -1;
+            s_kp[oo + i] = k;
+        }
+    }
+    __syncthreads();
+    if (fm.has_camera && fm.cam.k1 != 0.0) {
+        // cv::undistortPoints with P = K: 5 fixed-point iterations in double (camera.cpp:107-113)
+        const orbx_camera c = fm.cam;
+        const double ifx = 1. / c.fx, ify = 1. / c.fy;
+        for (int i = tid; i < count; i += blockDim.x) {
+            double x = s_kp[i].x, y = s_kp[i].y;
+            x = (x - c.cx) * ifx;
+            y = (y - c.cy) * ify;
+            const double x0 = x, y0 = y;
+            for (int j = 0; j < 5; j++) {
+                const double r2 = x * x + y * y;
+                const double icdist = 1. / (1 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+                const double dx = 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x);
+                const double dy = c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y;
+                x = (x0 - dx) * icdist;
+                y = (y0 - dy) * icdist;
+            }
+            s_kp[i].x = (float)(x * c.fx + c.cx);
+            s_kp[i].y = (float)(y * c.fy + c.cy);
+        }
+        __syncthreads();
+    }
+    if (fm.has_grid) {
+        // Frame::assignFeaturesToGrid / pointInGrid (frame.cpp:326-367)
+        const orbx_grid gr = fm.grid;
+        const int ncell = gr.grid_cols * gr.grid_rows;
+        auto cell_of = [&](const orbx_keypoint& k) -> int {
+            const int pos_y = (int)((k.y - gr.min_y) / gr.grid_size_y);
+            const int pos_x = (int)((k.x - gr.min_x) / gr.grid_size_x);
+            if (pos_y < 0 || pos_y >= gr.grid_rows || pos_x < 0 || pos_x >= gr.grid_cols) return -1;
+            return pos_x * gr.grid_rows + pos_y;
+        };
+        if (lvl == 0) {
+            count = compact_ordered(s_kp, count, lane, [&](const orbx_keypoint& k) { return cell_of(k) >= 0; });
+            if (lane == 0) s_cnt = count;
+        }
+        for (int i = tid; i <= ncell; i += blockDim.x) s_cells[i] = 0;
+        __syncthreads();
+        count = s_cnt;
+        for (int i = tid; i < count; i += blockDim.x) {
+            const int c = cell_of(s_kp[i]);
+            s_cell[i] = c;
+            atomicAdd(&s_cells[c + 1], 1);
+        }
+        __syncthreads();
+        if (lvl == 0) {
+            // inclusive scan of the per-cell counts by one wavefront -> CSR offsets
+            int carry = 0;
+            for (int base = 1; base <= ncell; base += 64) {
+                const int i = base + lane;
+                int v = i <= ncell ? s_cells[i] : 0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int u = __shfl_up(v, o);
+                    if (lane >= o) v += u;
+                }
+                if (i <= ncell) s_cells[i] = v + carry;
+                carry += __shfl(v, 63);
+            }
+        }
+        __syncthreads();
+        int* cs = cell_start + (size_t)b * (ncell + 1);
+        int* ci = cell_items + (size_t)b * kp_cap;
+        for (int i = tid; i <= ncell; i += blockDim.x) cs[i] = s_cells[i];
+        __syncthreads();
+        // fill: slots by atomics, then every cell's short list is put in ascending feature order (the reference
+        // appends features in index order)
+        for (int i = tid; i < count; i += blockDim.x) ci[atomicAdd(&s_cells[s_cell[i]], 1)] = i;
+        __syncthreads();
+        for (int c = tid; c < ncell; c += blockDim.x) {
+            const int i0 = cs[c], i1 = cs[c + 1];
+            for (int i = i0 + 1; i < i1; i++) {
+                const int v = ci[i];
+                int j = i - 1;
+                while (j >= i0 && ci[j] > v) { ci[j + 1] = ci[j]; j--; }
+                ci[j + 1] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (fm.has_camera && lvl == 0) {
+        // cv::ORB::compute -> runByImageBorder on the moved keypoints; the grid above is left as built, exactly as
+        // the reference leaves it
+        count = compact_ordered(s_kp, count, lane,
+                                [&](const orbx_keypoint& k) { return border_ok(k, fm.width, fm.height, fm.edge); });
+        if (lane == 0) s_cnt = count;
+    }
+    __syncthreads();
+    count = s_cnt;
+    orbx_keypoint* out = kps_out + (size_t)b * kp_cap;
+    for (int i = tid; i < count; i += blockDim.x) out[i] = s_kp[i];
+    if (tid == 0) { kp_counts[b] = count; status[b] = 0; }
 }
 
 // Packs the per-frame candidate lists back to back (offsets = exclusive prefix of totals) for one D2H copy.

@@ -1,5 +1,6 @@
 // Host-side logic of the orbx library (see host_logic.h).  Plain C++; no device code.
 #include "host_logic.h"
+#include "stdsel.h"
 
 #include <algorithm>
 #include <cmath>
@@ -144,6 +145,18 @@ orbx_status orbx_filter_matches(orbx_match* matches, int* count, int n_descripto
         if (good[i].train != good[i - 1].train) out.push_back(good[i]);
     std::copy(out.begin(), out.end(), matches);
     *count = (int)out.size();
+    return ORBX_OK;
+}
+
+// Host build of the device-side retainBest replay (stdsel.h), exposed so that the CPU tests can compare it with
+// the real std::nth_element / std::partition.
+orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, int32_t* perm_out, int* new_n) {
+    if (n < 0 || !new_n || (n > 0 && (!keys || !perm_out))) return ORBX_BAD_ARG;
+    std::vector<orbx::stdsel::Elem> a(n);
+    for (int i = 0; i < n; i++) a[i] = orbx::stdsel::Elem{keys[i], i};
+    const int m = orbx::stdsel::retain_best(a.data(), n, n_points);
+    for (int i = 0; i < m; i++) perm_out[i] = a[i].idx;
+    *new_n = m;
     return ORBX_OK;
 }
 

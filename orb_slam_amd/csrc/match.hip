@@ -280,9 +280,11 @@ __device__ __forceinline__ bool in_window(const orbx_keypoint& k, const Window& 
 // win_n[ref] = -1: point skipped; > kWinK: list too long, K10b gathers that point's window itself.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_window_gather(ProjArgs A) {
-    const int lane = threadIdx.x & 63;
+    // 16 lanes per reference point (a level-0 window spans ~30 grid cells): the work is a chain of dependent loads,
+    // so four points per wavefront quadruple the loads in flight
+    const int lane = threadIdx.x & 15;
     resolve_views(A, blockIdx.y);
-    const int ref_idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ref_idx = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (ref_idx >= A.n_ref) return;
     const orbx_grid& g = A.g;
     Window W;
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(256) void k_window_gather(ProjArgs A) {
     const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
     int2* list = A.win_list + (size_t)ref_idx * kWinK;
     int list_n = 0;
-    for (int cbase = 0; cbase < W.ncells; cbase += 64) {
+    for (int cbase = 0; cbase < W.ncells && list_n <= kWinK; cbase += 16) {
         const int c = cbase + lane;
-        int cnt = 0, i0 = 0, i1 = 0, cxi = 0, cyi = 0;
+        int i0 = 0, i1 = 0, cxi = 0, cyi = 0;
         if (c < W.ncells) {
             cxi = W.left + c / W.ncy;
             cyi = W.up + c % W.ncy;
@@ -303,20 +305,30 @@ __global__ __launch_bounds__(256) void k_window_gather(ProjArgs A) {
             i0 = A.cell_start[cell];
             i1 = A.cell_start[cell + 1];
         }
-        for (int i = i0; i < i1; i++) cnt += in_window(A.kps[A.cell_items[i]], W, cxi, cyi) ? 1 : 0;
+        // accepted items of this lane's cell: a bit mask for the first 32, the rest re-tested when written
+        unsigned acc = 0;
+        int cnt = 0;
+        for (int i = i0; i < i1; i++) {
+            const bool ok = in_window(A.kps[A.cell_items[i]], W, cxi, cyi);
+            if (ok && i - i0 < 32) acc |= 1u << (i - i0);
+            cnt += ok;
+        }
         int incl = cnt;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int v = __shfl_up(incl, o);
+        for (int o = 1; o < 16; o <<= 1) {
+            int v = __shfl_up(incl, o, 16);
             if (lane >= o) incl += v;
         }
-        const int total = __shfl(incl, 63);
+        const int total = __shfl(incl, 15, 16);
         int pos = list_n + incl - cnt;
         list_n += total;
         if (list_n > kWinK) break;
         for (int i = i0; i < i1; i++) {
-            const int idx = A.cell_items[i];
-            if (in_window(A.kps[idx], W, cxi, cyi)) list[pos++] = make_int2(idx, hamming32(rd, A.desc + (size_t)idx * 32));
+            const bool ok = i - i0 < 32 ? ((acc >> (i - i0)) & 1u) != 0 : in_window(A.kps[A.cell_items[i]], W, cxi, cyi);
+            if (ok) {
+                const int idx = A.cell_items[i];
+                list[pos++] = make_int2(idx, hamming32(rd, A.desc + (size_t)idx * 32));
+            }
         }
     }
     if (lane == 0) A.win_n[ref_idx] = list_n;
@@ -351,25 +363,42 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     int n_push = 0;
     const float factor = 1.0f / 30;
     const bool use_lists = A.win_n != nullptr;
-    // software prefetch of the next reference point's list entry for this lane
-    int next_n = -1;
-    int2 next_e = make_int2(-1, 0);
-    if (use_lists && A.n_ref > 0) {
-        next_n = A.win_n[0];
-        if (lane < next_n && next_n <= kWinK) next_e = A.win_list[lane];
+    // software prefetch, kPF reference points ahead: the list loads do not depend on anything the loop computes
+    constexpr int kPF = 8;
+    int pf_n[kPF];
+    int2 pf_e[kPF];
+#pragma unroll
+    for (int k = 0; k < kPF; k++) {
+        pf_n[k] = -1;
+        pf_e[k] = make_int2(-1, 0);
+        if (use_lists && k < A.n_ref) {
+            pf_n[k] = A.win_n[k];
+            pf_e[k] = A.win_list[(size_t)k * kWinK + lane];
+        }
     }
-    for (int ref_idx = 0; ref_idx < A.n_ref; ++ref_idx) {
+    for (int ref_base = 0; ref_base < A.n_ref; ref_base += kPF) {
+      int blk_n[kPF];
+      int2 blk_e[kPF];
+#pragma unroll
+      for (int k = 0; k < kPF; k++) {
+          blk_n[k] = pf_n[k];
+          blk_e[k] = pf_e[k];
+          const int nx = ref_base + kPF + k;
+          if (use_lists && nx < A.n_ref) {
+              pf_n[k] = A.win_n[nx];
+              pf_e[k] = A.win_list[(size_t)nx * kWinK + lane];
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < kPF; k++) {
+        const int ref_idx = ref_base + k;
+        if (ref_idx >= A.n_ref) break;
         int list_n = 0;
         int cur_n = 0;
         int2 cur_e = make_int2(-1, 0);
         if (use_lists) {
-            cur_n = next_n;
-            cur_e = next_e;
-            if (ref_idx + 1 < A.n_ref) {
-                next_n = A.win_n[ref_idx + 1];
-                next_e = make_int2(-1, 0);
-                if (lane < next_n && next_n <= kWinK) next_e = A.win_list[(size_t)(ref_idx + 1) * kWinK + lane];
-            }
+            cur_n = blk_n[k];
+            cur_e = blk_e[k];
             if (cur_n <= 0) continue;
         }
         // a window longer than kWinK (rare) is gathered again here, sequentially, for this point only
@@ -450,6 +479,7 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
             }
             if (overflow) {
                 if (lane == 0) *A.status = 1;
+                ref_base = A.n_ref;  // leave both loops
                 break;
             }
             __syncthreads();
@@ -488,6 +518,7 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
             }
         }
         __syncthreads();
+      }
     }
     __syncthreads();
     if (MODE == 0 && A.check_orientation) {
@@ -778,10 +809,10 @@ static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g,
     A.win_overflow = h->d_win_over.p;
     const size_t shmem = sizeof(int32_t) * (size_t)n;
     if (mode == 0) {
-        hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(n_ref, 4), 1), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(n_ref, 16), 1), dim3(256), 0, s, A);
         hipLaunchKernelGGL(k_projection_match<0>, dim3(1), dim3(64), shmem, s, A);
     } else {
-        hipLaunchKernelGGL(k_window_gather<1>, dim3(div_up(n_ref, 4), 1), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(k_window_gather<1>, dim3(div_up(n_ref, 16), 1), dim3(256), 0, s, A);
         hipLaunchKernelGGL(k_projection_match<1>, dim3(1), dim3(64), shmem, s, A);
     }
     ORBX_HIP(hipGetLastError());
@@ -869,7 +900,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     A.win_n = h->d_win_n.p;
     A.win_list = h->d_win_list.p;
     A.win_overflow = h->d_win_over.p;
-    hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 4), n_pairs), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_projection_match<0>, dim3(n_pairs), dim3(64), sizeof(int32_t) * (size_t)kp_capacity, s, A);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

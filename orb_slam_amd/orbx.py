@@ -27,7 +27,8 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best",
+    "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
 
@@ -218,6 +219,9 @@ class Extractor:
                                                     C.byref(grid) if grid is not None else None),
                "orbx_extractor_set_frame_model")
 
+    def set_device_select(self, enabled):
+        _check(lib().orbx_extractor_set_device_select(self._h, int(enabled)), "orbx_extractor_set_device_select")
+
     def device_grid(self):
         a, b = C.c_void_p(), C.c_void_p()
         _check(lib().orbx_extractor_device_grid(self._h, C.byref(a), C.byref(b)), "orbx_extractor_device_grid")
@@ -231,9 +235,9 @@ class Extractor:
         return kp.value, desc.value, cnt.value, cap.value
 
     def last_timings(self):
-        ms = np.zeros(8, np.float32)
-        n = lib().orbx_extractor_last_timings(self._h, _p(ms), 8)
-        names = ["gray", "resize", "fast", "nms", "emit", "harris", "blur", "brief"]
+        ms = np.zeros(9, np.float32)
+        n = lib().orbx_extractor_last_timings(self._h, _p(ms), 9)
+        names = ["gray", "resize", "fast", "nms", "emit", "harris", "blur", "brief", "select"]
         return dict(zip(names[:n], ms[:n].tolist()))
 
 
@@ -374,6 +378,15 @@ def assign_grid(g, kps):
     n = C.c_int(len(k))
     _check(lib().orbx_assign_grid(C.byref(g), _p(k), C.byref(n), _p(start), _p(items)), "orbx_assign_grid")
     return k[:n.value].copy(), start, items[:n.value].copy()
+
+
+def selftest_retain_best(keys, n_points):
+    keys = np.ascontiguousarray(keys, np.float32)
+    perm = np.zeros(max(len(keys), 1), np.int32)
+    n = C.c_int()
+    _check(lib().orbx_selftest_retain_best(_p(keys), len(keys), n_points, _p(perm), C.byref(n)),
+           "orbx_selftest_retain_best")
+    return perm[:n.value].copy()
 
 
 def ransac_make_sets(n, iterations, seed0):

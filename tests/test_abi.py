@@ -77,3 +77,40 @@ def test_ransac_sets_match_oracle(oracle):
         assert np.array_equal(orbx.ransac_make_sets(n, it, seed), oracle.ransac_sets(n, it, seed))
     s = orbx.ransac_make_sets(50, 20, 2)
     assert all(len(set(r.tolist())) == 8 for r in s)
+
+
+def test_retain_best_replay_matches_libstdcxx(oracle):
+    """The library's replay of std::nth_element + std::partition leaves the kept keypoints in exactly the order the
+    real libstdc++ calls do, including tie-heavy inputs (FAST scores are small integers) and the heap-select path."""
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (0, 1, 2, 3, 4, 5, 17, 100, 1000, 4583):
+        for kind in ("ties", "float", "sorted", "reversed", "const"):
+            if kind == "ties":
+                keys = rng.integers(20, 60, n).astype(np.float32)
+            elif kind == "float":
+                keys = rng.normal(size=n).astype(np.float32)
+            elif kind == "sorted":
+                keys = np.arange(n, dtype=np.float32)
+            elif kind == "reversed":
+                keys = np.arange(n, dtype=np.float32)[::-1].copy()
+            else:
+                keys = np.full(n, 7, np.float32)
+            for npts in sorted({0, 1, 2, n // 3, n // 2, max(n - 1, 0), n, n + 5}):
+                cases.append((keys, npts))
+    # median-of-3 killer sequence: drives introselect into its heap-select fallback
+    n = 4096
+    k = np.zeros(n, np.float32)
+    half = n // 2
+    for i in range(half):
+        if i % 2 == 0:
+            k[i] = i + 1
+        else:
+            k[i] = half + i + (half % 2)
+    k[half:] = 2 * (np.arange(half) + 1)
+    cases.append((-k, 1000))
+    cases.append((k, 37))
+    for keys, npts in cases:
+        a = orbx.selftest_retain_best(keys, npts)
+        b = oracle.retain_best(keys, npts)
+        assert np.array_equal(a, b), (len(keys), npts)

@@ -131,13 +131,20 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     dev = torch.from_numpy(np.stack(frames)).cuda()
     torch.cuda.synchronize()
     cap = 1500
-    kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
-    for f, img in enumerate(frames):
+    ora = []
+    for img in frames:
         ok_ = oracle.detect(p, img)
-        ok2, od = oracle.compute(p, img, ok_)
-        assert counts[f] == len(ok2)
-        assert np.array_equal(kps[f, :counts[f]], ok2.astype(orbx.KP_DTYPE))
-        assert np.array_equal(desc[f, :counts[f]], od)
+        ora.append(oracle.compute(p, img, ok_))
+    for device_select in (True, False):  # both forms of the selection step must give the reference order
+        ex.set_device_select(device_select)
+        kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+        for f, (ok2, od) in enumerate(ora):
+            assert counts[f] == len(ok2), (device_select, f)
+            assert np.array_equal(kps[f, :counts[f]], ok2.astype(orbx.KP_DTYPE)), (device_select, f)
+            assert np.array_equal(desc[f, :counts[f]], od), (device_select, f)
+    with pytest.raises(orbx.OrbxError) as e:
+        ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, 500)
+    assert e.value.status == orbx.CAPACITY
     ex.close()
 
 
@@ -219,6 +226,12 @@ def test_projection_matchers_bit_exact(oracle, matcher, ex1000, test_images):
         om = oracle.match_projection_points(og, start, items, k0, d0, in_view, proj, pred, vcos, dr, sf, radius, ratio)
         assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE)), (radius, ratio)
     assert len(m) > 20
+
+
+class _DevView:
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
 
 
 def _two_view(rng, n, outliers, noise=0.5, planar=False):
@@ -328,7 +341,23 @@ def test_frame_model_batch_and_batched_projection(oracle, test_images):
               np.roll(test_images[1], -2, axis=0).copy(), test_images[0]]
     dev = torch.from_numpy(np.stack(frames)).cuda()
     torch.cuda.synchronize()
+    ex.set_device_select(False)
+    kps_h, counts_h, desc_h = ex.extract_batch(dev.data_ptr(), B, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    import ctypes
+    cs_h, ci_h = ex.device_grid()
+    ncell = grid.grid_cols * grid.grid_rows
+    grid_host = (torch.as_tensor(_DevView(cs_h, (B, ncell + 1), "<i4"), device="cuda").cpu().numpy().copy(),
+                 torch.as_tensor(_DevView(ci_h, (B, cap), "<i4"), device="cuda").cpu().numpy().copy())
+    ex.set_device_select(True)
     kps, counts, desc = ex.extract_batch(dev.data_ptr(), B, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    cs_d, ci_d = ex.device_grid()
+    grid_dev = (torch.as_tensor(_DevView(cs_d, (B, ncell + 1), "<i4"), device="cuda").cpu().numpy(),
+                torch.as_tensor(_DevView(ci_d, (B, cap), "<i4"), device="cuda").cpu().numpy())
+    assert np.array_equal(counts, counts_h) and np.array_equal(grid_dev[0], grid_host[0])
+    for f in range(B):
+        assert np.array_equal(kps[f, :counts[f]], kps_h[f, :counts[f]]) and np.array_equal(desc[f, :counts[f]], desc_h[f, :counts[f]])
+        nk = grid_dev[0][f, -1]
+        assert np.array_equal(grid_dev[1][f, :nk], grid_host[1][f, :nk])
     ora = []
     for f, img in enumerate(frames):
         k = oracle.detect(p, img)
