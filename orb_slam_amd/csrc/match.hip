@@ -170,6 +170,8 @@ struct ProjArgs {
     int32_t* win_n;             // [pairs][pair_stride]
     int2* win_list;             // [pairs][pair_stride][kWinK] (feature index, Hamming distance)
     int32_t* win_overflow;      // [pairs]
+    int32_t* need_slow;         // [pairs] or NULL: K10c sets it for a pair with an over-long window; K10b then runs
+                                // only for flagged pairs
 };
 
 __device__ __forceinline__ int hamming32(const uint8_t* a, const uint8_t* b) {
@@ -186,6 +188,17 @@ __device__ __forceinline__ int hamming32(const uint8_t* a, const uint8_t* b) {
 // index order inside a cell), compute the Hamming distances in parallel, and lane 0 resolves the ordered list.
 // MODE 0 = frame-to-frame (orb_matcher.cpp:115-255), MODE 1 = map points (orb_matcher.cpp:257-352).
 constexpr int kWinK = 64;  // entries per reference point in the pre-gathered window lists
+
+// Minimum over the 64 lanes with DPP row operations; every lane must be active.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast15
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 struct Window {
     float px, py, radius_scaled;
@@ -216,6 +229,7 @@ __device__ __forceinline__ void resolve_views(ProjArgs& A, int pair) {
     A.pushes += po * 2;
     A.status += pair;
     if (A.n_matches) A.n_matches += pair;
+    if (A.need_slow) A.need_slow += pair;
     if (A.win_n) {
         A.win_n += po;
         A.win_list += po * kWinK;
@@ -348,6 +362,7 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     __shared__ int32_t s_hist[30];
     const int lane = threadIdx.x;
     const orbx_grid g = A.g;
+    if (A.need_slow && A.need_slow[blockIdx.x] == 0) return;
     resolve_views(A, blockIdx.x);
     {
         // flags cover the whole frame slot in the batched form: a stale grid entry (the reference's compute() may
@@ -405,18 +420,12 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
         if (use_lists && cur_n <= kWinK) {
             const bool valid = lane < cur_n && !(s_matched[cur_e.x] > 0);
             if (MODE == 0) {
-                // min distance, last in scan order wins ties (`<=` in orb_matcher.cpp:222)
-                unsigned long long key = valid ? (((unsigned long long)(unsigned)cur_e.y << 32) | (unsigned)(63 - lane))
-                                               : ~0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned long long other = __shfl_xor(key, o);
-                    key = other < key ? other : key;
-                }
-                if (key == ~0ull) continue;
-                const int min_d = (int)(key >> 32);
-                const int wl = 63 - (int)(key & 0xffffffffu);
-                const int id = __shfl(cur_e.x, wl);
+                // min distance, last in scan order wins ties (`<=` in orb_matcher.cpp:222): one 32-bit key per lane,
+                // reduced with DPP row operations (no LDS round trips)
+                const unsigned key = wave_min_u32(valid ? (((unsigned)cur_e.y << 8) | (unsigned)(63 - lane)) : ~0u);
+                if (key == ~0u) continue;
+                const int min_d = (int)(key >> 8);
+                const int id = __builtin_amdgcn_readlane(cur_e.x, 63 - (int)(key & 0xffu));
                 if (min_d <= 100) {
                     if (lane == 0) {
                         s_matched[id] = ref_idx;
@@ -427,7 +436,9 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
                             n_push++;
                         }
                     }
-                    __syncthreads();
+                    // one wavefront: LDS operations retire in program order, so the flag written above is seen by
+                    // the next point's lookup without a barrier (and without waiting for the global stores)
+                    __builtin_amdgcn_wave_barrier();
                 }
                 continue;
             }
@@ -563,6 +574,169 @@ __global__ __launch_bounds__(64) void k_projection_match(ProjArgs A) {
     if (lane == 0 && A.n_matches) *A.n_matches = cnt;
 }
 
+// Frame-to-frame rule for ONE reference point without a pre-gathered list: every lane scans grid cells of the
+// window, keeps its best (distance, scan position) among the still-free features, and the wave takes the minimum
+// distance with the LAST scan position on ties (`<=` in orb_matcher.cpp:222).  Returns (distance << 32 | feature)
+// or -1 when the window holds no free feature.
+__device__ __noinline__ long long best_in_window_scan(const ProjArgs& A, int ref_idx, const int32_t* s_matched,
+                                                      int lane) {
+    Window W;
+    if (!window_of<0>(A, ref_idx, W)) return -1;
+    const orbx_grid& g = A.g;
+    const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
+    unsigned long long best = ~0ull;  // dist << 44 | (inverted scan position: cell << 12 | item)
+    int best_id = -1;
+    for (int cbase = 0; cbase < W.ncells; cbase += 64) {
+        const int c = cbase + lane;
+        if (c >= W.ncells) continue;
+        const int cxi = W.left + c / W.ncy, cyi = W.up + c % W.ncy;
+        const int cell = cxi * g.grid_rows + cyi;
+        const int i0 = A.cell_start[cell], i1 = A.cell_start[cell + 1];
+        for (int i = i0; i < i1; i++) {
+            const int idx = A.cell_items[i];
+            if (s_matched[idx] > 0 || !in_window(A.kps[idx], W, cxi, cyi)) continue;
+            const unsigned long long d = (unsigned)hamming32(rd, A.desc + (size_t)idx * 32);
+            const unsigned long long pos = ((unsigned long long)c << 12) | (unsigned)min(i - i0, 4095);
+            const unsigned long long key = (d << 44) | ((1ull << 44) - 1 - pos);
+            if (key < best) { best = key; best_id = idx; }
+        }
+    }
+    unsigned long long w = best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(w, o);
+        w = other < w ? other : w;
+    }
+    if (w == ~0ull) return -1;
+    const unsigned long long bal = __ballot(best == w);
+    const int src = __ffsll((long long)bal) - 1;
+    const int id = __shfl(best_id, src);
+    return (long long)(((w >> 44) << 32) | (unsigned)id);
+}
+
+// K10c: the batched frame-to-frame resolve in its lean form: window lists only (K10a), all per-pair state in LDS
+// (matched flags, distances, histogram pushes), no global store inside the sequential loop, DPP wave minimum.
+// A pair that meets a window longer than kWinK is flagged and redone by K10b.
+__global__ __launch_bounds__(64) void k_resolve_lists(ProjArgs A) {
+    extern __shared__ int32_t s_mem[];
+    __shared__ int32_t s_hist[30];
+    const int lane = threadIdx.x;
+    const int pair = blockIdx.x;
+    const int cap = (int)A.kp_stride;
+    int32_t* s_matched = s_mem;            // [cap]
+    int32_t* s_dists = s_mem + cap;        // [cap]
+    int32_t* s_push = s_mem + 2 * cap;     // [2 * cap]
+    resolve_views(A, pair);
+    for (int i = lane; i < cap; i += 64) {
+        s_matched[i] = -1;
+        s_dists[i] = -1;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    __syncthreads();
+    int n_push = 0;
+    constexpr int kPF = 8;
+    int pf_n[kPF];
+    int2 pf_e[kPF];
+#pragma unroll
+    for (int k = 0; k < kPF; k++) {
+        pf_n[k] = -1;
+        pf_e[k] = make_int2(-1, 0);
+        if (k < A.n_ref) {
+            pf_n[k] = A.win_n[k];
+            pf_e[k] = A.win_list[(size_t)k * kWinK + lane];
+        }
+    }
+    bool slow = false;
+    for (int ref_base = 0; ref_base < A.n_ref && !slow; ref_base += kPF) {
+        int blk_n[kPF];
+        int2 blk_e[kPF];
+#pragma unroll
+        for (int k = 0; k < kPF; k++) {
+            blk_n[k] = pf_n[k];
+            blk_e[k] = pf_e[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kPF; k++) {
+            const int nx = ref_base + kPF + k;
+            if (nx < A.n_ref) {
+                pf_n[k] = A.win_n[nx];
+                pf_e[k] = A.win_list[(size_t)nx * kWinK + lane];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPF; k++) {
+            const int ref_idx = ref_base + k;
+            const int cur_n = blk_n[k];
+            if (ref_idx >= A.n_ref || cur_n <= 0) continue;
+            int min_d, id;
+            if (cur_n > kWinK) {
+                // window longer than the pre-gathered list (dense clusters): scan the grid for this point here
+                const long long r = best_in_window_scan(A, ref_idx, s_matched, lane);
+                if (r < 0) continue;
+                min_d = (int)(r >> 32);
+                id = (int)(r & 0xffffffff);
+            } else {
+                const int2 e = blk_e[k];
+                const bool valid = lane < cur_n && !(s_matched[e.x] > 0);
+                const unsigned key = wave_min_u32(valid ? (((unsigned)e.y << 8) | (unsigned)(63 - lane)) : ~0u);
+                if (key == ~0u) continue;
+                min_d = (int)(key >> 8);
+                id = __builtin_amdgcn_readlane(e.x, 63 - (int)(key & 0xffu));
+            }
+            if (min_d > 100) continue;
+            if (lane == 0) {
+                s_matched[id] = ref_idx;
+                s_dists[id] = min_d;
+                s_push[2 * n_push] = ref_idx;
+                s_push[2 * n_push + 1] = id;
+                n_push++;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    (void)slow;
+    __syncthreads();
+    if (A.check_orientation) {
+        n_push = __builtin_amdgcn_readlane(n_push, 0);
+        const float factor = 1.0f / 30;
+        for (int i = lane; i < n_push; i += 64) {
+            float rot = A.ref_kps[s_push[2 * i]].angle - A.kps[s_push[2 * i + 1]].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin < 0 || bin >= 30) bin = -1;
+            else atomicAdd(&s_hist[bin], 1);
+            s_push[2 * i] = bin;
+        }
+        __syncthreads();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = lane; i < n_push; i += 64) {
+            const int bin = s_push[2 * i];
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) s_matched[s_push[2 * i + 1]] = 0;
+        }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int i = lane; i < cap; i += 64) {
+        const int m = i < A.n ? s_matched[i] : -1;
+        A.matched[i] = m;
+        A.dists[i] = s_dists[i];
+        cnt += m > 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0 && A.n_matches) *A.n_matches = cnt;
+}
+
 }  // namespace
 
 struct orbx_matcher {
@@ -575,6 +749,7 @@ struct orbx_matcher {
     DevBuf<orbx_keypoint> d_kp, d_refkp;
     DevBuf<int32_t> d_win_n, d_win_over;
     DevBuf<int2> d_win_list;
+    size_t fast_lds_attr = 0;
     std::vector<unsigned long long> h_best;
 };
 
@@ -900,7 +1075,17 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     A.win_n = h->d_win_n.p;
     A.win_list = h->d_win_list.p;
     A.win_overflow = h->d_win_over.p;
+    A.need_slow = h->d_win_over.p;
     hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A);
+    const size_t fast_lds = sizeof(int32_t) * 4 * (size_t)kp_capacity;
+    if (fast_lds > 48 * 1024 && fast_lds > h->fast_lds_attr) {
+        ORBX_HIP(hipFuncSetAttribute((const void*)k_resolve_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
+        h->fast_lds_attr = fast_lds;
+    }
+    hipLaunchKernelGGL(k_resolve_lists, dim3(n_pairs), dim3(64), fast_lds, s, A);
+    // pairs flagged by the lean kernel (a window longer than its lists hold) are redone by the general one
+    A.win_n = nullptr;
+    A.win_list = nullptr;
     hipLaunchKernelGGL(k_projection_match<0>, dim3(n_pairs), dim3(64), sizeof(int32_t) * (size_t)kp_capacity, s, A);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
