@@ -38,6 +38,12 @@ struct orbx_extractor {
     std::vector<Tile> tiles;
     std::vector<Strip> strips;
     std::vector<Coef> coefs;
+    std::vector<CoefX> coefx;
+    std::vector<CoefY> coefy;
+    struct ResizePlan { int cx_off, cy_off, ax_begin, n_dwords; };
+    ResizePlan rplan[kMaxLevels];
+    DevBuf<CoefX> d_coefx;
+    DevBuf<CoefY> d_coefy;
     DevBuf<Tile> d_tiles;
     DevBuf<Strip> d_strips;
     DevBuf<Coef> d_coefs;
@@ -186,6 +192,39 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
             fill(S.h, L.h);
         }
     }
+    // atlas-indexed coefficient groups of the dword-wise resize (reflect-101 border folded in)
+    h->coefx.clear();
+    h->coefy.clear();
+    for (int level = 1; level < nlevels; level++) {
+        const LevelInfo& L = g.L[level];
+        const LevelInfo& S = g.L[level - 1];
+        orbx_extractor::ResizePlan& rp = h->rplan[level];
+        auto refl = [](int p, int len) {
+            if (len == 1) return 0;
+            while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * (len - 1) - p;
+            return p;
+        };
+        const int x_first = L.x - border, x_last = L.x + L.w + border;  // padded rect [x_first, x_last)
+        rp.ax_begin = x_first & ~3;
+        rp.n_dwords = (x_last - rp.ax_begin + 3) / 4;
+        rp.cx_off = (int)h->coefx.size();
+        for (int i = 0; i < rp.n_dwords * 4; i++) {
+            const int ax = rp.ax_begin + i;
+            CoefX c{0, 0};
+            if (ax >= x_first && ax < x_last) {
+                const Coef& k = h->coefs[L.coef_x + refl(ax - L.x, L.w)];
+                const int o1 = std::min(k.ofs + 1, S.w - 1);
+                c.src_ax = (int16_t)(S.x + k.ofs);
+                c.w1f = (uint16_t)((k.w1 & 0x1ff) | ((o1 != k.ofs) ? 0x4000 : 0) | 0x8000);
+            }
+            h->coefx.push_back(c);
+        }
+        rp.cy_off = (int)h->coefy.size();
+        for (int ty = 0; ty < L.h + 2 * border; ty++) {
+            const Coef& k = h->coefs[L.coef_y + refl(ty - border, L.h)];
+            h->coefy.push_back(CoefY{S.y + k.ofs, S.y + std::min(k.ofs + 1, S.h - 1), k.w1});
+        }
+    }
     g.total_words = words;
     g.total_tiles = (int)h->tiles.size();
     h->atlas_bytes = (size_t)g.atlas_w * g.atlas_h;
@@ -193,6 +232,12 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
     ORBX_TRY(h->d_strips.ensure(h->strips.size()));
     ORBX_HIP(hipMemcpyAsync(h->d_strips.p, h->strips.data(), h->strips.size() * sizeof(Strip), hipMemcpyHostToDevice, h->stream));
     ORBX_TRY(h->d_coefs.ensure(std::max<size_t>(h->coefs.size(), 1)));
+    ORBX_TRY(h->d_coefx.ensure(std::max<size_t>(h->coefx.size(), 4)));
+    ORBX_TRY(h->d_coefy.ensure(std::max<size_t>(h->coefy.size(), 1)));
+    if (!h->coefx.empty()) {
+        ORBX_HIP(hipMemcpyAsync(h->d_coefx.p, h->coefx.data(), h->coefx.size() * sizeof(CoefX), hipMemcpyHostToDevice, h->stream));
+        ORBX_HIP(hipMemcpyAsync(h->d_coefy.p, h->coefy.data(), h->coefy.size() * sizeof(CoefY), hipMemcpyHostToDevice, h->stream));
+    }
     ORBX_HIP(hipMemcpyAsync(h->d_tiles.p, h->tiles.data(), h->tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, h->stream));
     if (!h->coefs.empty())
         ORBX_HIP(hipMemcpyAsync(h->d_coefs.p, h->coefs.data(), h->coefs.size() * sizeof(Coef), hipMemcpyHostToDevice, h->stream));
@@ -207,9 +252,9 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
 orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     const Geom& g = h->geom;
     size_t A = h->atlas_bytes;
-    ORBX_TRY(h->d_atlas.ensure(A * frames));
+    ORBX_TRY(h->d_atlas.ensure(A * frames + 64));  // slack: dword-wise kernels read up to 11 bytes past a span
     ORBX_TRY(h->d_score.ensure(A * frames));
-    ORBX_TRY(h->d_blur.ensure(A * frames));
+    ORBX_TRY(h->d_blur.ensure(A * frames + 64));
     ORBX_TRY(h->d_mask.ensure((size_t)g.total_words * frames));
     // candidate capacity: a strict 3x3 maximum can occur at most once per 2x2 pixels; a quarter of that bound is
     // ample for natural images and overflow is reported, not truncated.
@@ -245,9 +290,10 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     T.end(ST_GRAY, s);
     T.begin(ST_RESIZE, s);
     for (int l = 1; l < g.nlevels; l++) {
-        dim3 grid(div_up(g.L[l].w + 2 * border, 256), g.L[l].h + 2 * border, frames);
-        hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l - 1], g.L[l],
-                           h->d_coefs.p, border);
+        const orbx_extractor::ResizePlan& rp = h->rplan[l];
+        dim3 grid(div_up(rp.n_dwords, 64), div_up(g.L[l].h + 2 * border, 4), frames);
+        hipLaunchKernelGGL(k_resize_level4, grid, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l], border,
+                           h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
     }
     T.end(ST_RESIZE, s);
     T.begin(ST_FAST, s);
@@ -285,9 +331,10 @@ orbx_status run_pyramid(orbx_extractor* h, const uint8_t* d_images, int frames, 
     h->timer.end(ST_GRAY, s);
     h->timer.begin(ST_RESIZE, s);
     for (int l = 1; l < g.nlevels; l++) {
-        dim3 gr(div_up(g.L[l].w + 2 * border, 256), g.L[l].h + 2 * border, frames);
-        hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l - 1], g.L[l],
-                           h->d_coefs.p, border);
+        const orbx_extractor::ResizePlan& rp = h->rplan[l];
+        dim3 gr(div_up(rp.n_dwords, 64), div_up(g.L[l].h + 2 * border, 4), frames);
+        hipLaunchKernelGGL(k_resize_level4, gr, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l], border,
+                           h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
     }
     h->timer.end(ST_RESIZE, s);
     ORBX_HIP(hipGetLastError());
@@ -456,7 +503,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_pattern.release();
+    h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_coefx.release(); h->d_coefy.release(); h->d_pattern.release();
     h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
     h->d_mask.release(); h->d_cand.release(); h->d_packed.release();
     h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();

@@ -56,6 +56,62 @@ __global__ void k_resize_level(uint8_t* __restrict__ atlas, size_t atlas_bytes, 
     base[(size_t)(dst.y - border + ty) * aw + (dst.x - border + tx)] = (uint8_t)((v + (1u << 15)) >> 16);
 }
 
+// K2 (dword-wise): level l from level l-1 by cv::resize(INTER_LINEAR_EXACT), border included.  A lane produces four
+// adjacent atlas pixels: one 16-byte coefficient group (atlas-indexed, reflect-101 folded in on the host), three
+// aligned dwords per source row covering the (at most 7 pixel wide) source span, one dword store.
+__device__ __forceinline__ unsigned pick_byte(unsigned d0, unsigned d1, unsigned d2, int k) {
+    const unsigned d = k < 4 ? d0 : (k < 8 ? d1 : d2);
+    return (d >> ((k & 3) * 8)) & 0xffu;
+}
+
+__global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw,
+                                                       LevelInfo dst, int border, const CoefX* __restrict__ cxs,
+                                                       const CoefY* __restrict__ cys, int ax_begin, int n_dwords) {
+    const int dc = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dc >= n_dwords || ty >= dst.h + 2 * border) return;
+    const CoefY cy = cys[ty];
+    const uint4 raw = *(const uint4*)(cxs + dc * 4);
+    const unsigned cw[4] = {raw.x, raw.y, raw.z, raw.w};
+    int sx[4], w1[4], step[4];
+    bool ok[4];
+    int lo = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        sx[j] = (int)(short)(cw[j] & 0xffffu);
+        const unsigned f = cw[j] >> 16;
+        w1[j] = (int)(f & 0x1ffu);
+        step[j] = (int)((f >> 14) & 1u);
+        ok[j] = (f >> 15) != 0;
+        if (ok[j]) lo = min(lo, sx[j]);
+    }
+    if (lo == 0x7fffffff) return;
+    const int base = lo & ~3;
+    uint8_t* fb = atlas + (size_t)blockIdx.z * atlas_bytes;
+    const unsigned* r0 = (const unsigned*)(fb + (size_t)cy.row0 * aw + base);
+    const unsigned* r1 = (const unsigned*)(fb + (size_t)cy.row1 * aw + base);
+    const unsigned a0 = r0[0], a1 = r0[1], a2 = r0[2];
+    const unsigned b0 = r1[0], b1 = r1[1], b2 = r1[2];
+    const unsigned wy1 = (unsigned)cy.w1, wy0 = 256u - wy1;
+    unsigned out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = ok[j] ? sx[j] - base : 0;
+        const unsigned wx1 = (unsigned)w1[j], wx0 = 256u - wx1;
+        const unsigned h0 = wx0 * pick_byte(a0, a1, a2, k) + wx1 * pick_byte(a0, a1, a2, k + step[j]);
+        const unsigned h1 = wx0 * pick_byte(b0, b1, b2, k) + wx1 * pick_byte(b0, b1, b2, k + step[j]);
+        const unsigned v = wy0 * h0 + wy1 * h1;
+        out |= ((v + (1u << 15)) >> 16) << (8 * j);
+    }
+    uint8_t* d = fb + (size_t)(dst.y - border + ty) * aw + ax_begin + dc * 4;
+    if (ok[0] && ok[1] && ok[2] && ok[3]) *(unsigned*)d = out;
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (ok[j]) d[j] = (uint8_t)(out >> (8 * j));
+    }
+}
+
 // 9 contiguous set bits in a circular 16-bit mask.
 __device__ __forceinline__ bool has_arc9(unsigned m) {
     m |= m << 16;

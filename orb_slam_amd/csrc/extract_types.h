@@ -54,6 +54,18 @@ struct Strip {
     int16_t y0;    // first level row
 };
 
+// Resize coefficients indexed by ATLAS position (reflect-101 border already folded in), so that a lane's four
+// adjacent output pixels read one aligned 16-byte entry group.
+struct CoefX {
+    int16_t src_ax;    // atlas x of the left source sample
+    uint16_t w1f;      // bits 0-8: Q8 weight of the right sample (0..256); bit 14: right sample = left + 1 (else
+                       // the same sample); bit 15: pixel lies inside the padded level rect
+};
+struct CoefY {
+    int32_t row0, row1;  // atlas rows of the two source samples
+    int32_t w1;          // Q8 weight of the lower sample
+};
+
 struct Tile {
     int16_t level, pad;
     int16_t x0, y0;
