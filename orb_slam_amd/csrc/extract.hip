@@ -297,13 +297,9 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     }
     T.end(ST_RESIZE, s);
     T.begin(ST_FAST, s);
-    hipLaunchKernelGGL(k_fast_score, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p, A, g,
-                       h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255));
+    hipLaunchKernelGGL(k_fast_nms<false>, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p,
+                       h->d_mask.p, A, g, h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255), 0);
     T.end(ST_FAST, s);
-    T.begin(ST_NMS, s);
-    hipLaunchKernelGGL(k_nms_mask, dim3(div_up(g.total_words, 4), frames), dim3(256), 0, s, h->d_score.p,
-                       h->d_mask.p, A, g);
-    T.end(ST_NMS, s);
     T.begin(ST_EMIT, s);
     hipLaunchKernelGGL(k_emit, dim3(frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, h->d_cand.p,
                        h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
@@ -555,6 +551,15 @@ orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, ui
     ORBX_HIP(hipSetDevice(h->device));
     const uint8_t* src = what == 0 ? h->d_atlas.p : what == 1 ? h->d_score.p : what == 2 ? h->d_blur.p : nullptr;
     if (!src) return ORBX_BAD_ARG;
+    if (what == 1) {
+        // the detect stage stores scores only where keypoints survive; fill in the whole plane of this frame
+        if (!h->pyramid_valid) return ORBX_BAD_ARG;
+        ORBX_HIP(hipMemsetAsync(h->d_score.p + (size_t)frame * h->atlas_bytes, 0, h->atlas_bytes, h->stream));
+        hipLaunchKernelGGL(k_fast_nms<true>, dim3(h->geom.total_tiles, 1), dim3(256), 0, h->stream, h->d_atlas.p,
+                           h->d_score.p, h->d_mask.p, h->atlas_bytes, h->geom, h->d_tiles.p,
+                           std::min(std::max(h->prm.score_threshold, 0), 255), frame);
+        ORBX_HIP(hipGetLastError());
+    }
     ORBX_HIP(hipStreamSynchronize(h->stream));
     ORBX_HIP(hipMemcpy(out, src + (size_t)frame * h->atlas_bytes, h->atlas_bytes, hipMemcpyDeviceToHost));
     return ORBX_OK;

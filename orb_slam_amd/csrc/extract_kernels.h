@@ -122,101 +122,135 @@ __device__ __forceinline__ bool has_arc9(unsigned m) {
     return r != 0;
 }
 
-// K3: FAST-9/16 corner score of every level pixel (cv::FAST_t<16> + cornerScore<16>); 0 = not a corner.
-// One 64x16 tile per workgroup, staged in LDS with a 3-pixel halo.
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
-                                                    size_t atlas_bytes, Geom g, const Tile* __restrict__ tiles,
-                                                    int threshold) {
-    __shared__ uint8_t t[kTileH + 6][kTileW + 8];
+// K3+K4a fused: FAST-9/16 score and 3x3 strict non-max suppression of one 64 x kTileH tile, never leaving LDS.
+//   phase 1  every pixel of the tile (plus a one-pixel ring for the suppression) takes the four-point compass test,
+//            evaluated on 64-bit lane masks with scalar logic; the pixels that pass (under a tenth) are queued;
+//   phase 2  the queued pixels get their cornerScore with full lanes; the score itself says whether the
+//            nine-contiguous test holds;
+//   phase 3  suppression + border rule -> one ballot word per tile row; the score byte is stored only where a
+//            keypoint survives (all the emission reads).  DENSE also stores every score of the tile (tests).
+constexpr int kFPitch = 80;              // LDS bytes per staged row: 64 + 2*4 halo + 3 alignment, rounded up
+constexpr int kFRows = kTileH + 8;
+constexpr int kSW = kTileW + 2, kSH = kTileH + 2;
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
+                                                  unsigned long long* __restrict__ mask, size_t atlas_bytes, Geom g,
+                                                  const Tile* __restrict__ tiles, int threshold, int frame0) {
+    __shared__ unsigned t32[kFRows * kFPitch / 4];
+    __shared__ unsigned s32[(kSW * kSH + 3) / 4];
+    __shared__ unsigned short queue[kSW * kSH];
+    __shared__ int q_count;
+    uint8_t* t = (uint8_t*)t32;
+    uint8_t* st = (uint8_t*)s32;
     const Tile tl = tiles[blockIdx.x];
     const LevelInfo L = g.L[tl.level];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y + frame0;
     const int aw = g.atlas_w;
-    const uint8_t* base = atlas + (size_t)b * atlas_bytes;
-    const int ax0 = L.x + tl.x0 - 3, ay0 = L.y + tl.y0 - 3;
-    for (int i = threadIdx.x; i < (kTileH + 6) * (kTileW + 6); i += 256) {
-        int r = i / (kTileW + 6), c = i - r * (kTileW + 6);
-        int ax = min(max(ax0 + c, 0), aw - 1), ay = min(max(ay0 + r, 0), g.atlas_h - 1);
-        t[r][c] = base[(size_t)ay * aw + ax];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lo = max(3, g.edge);
+    const bool level_ok = g.edge <= 0 || (L.w > 2 * g.edge && L.h > 2 * g.edge);
+    // pixels whose score can matter: the keypoint area [lo, w-lo) grown by one, inside the FAST domain [3, w-3)
+    const int in = DENSE ? 3 : max(lo - 1, 3);
+    const int xs = max(tl.x0 - 1, in), xe = min(tl.x0 + kTileW + 1, L.w - in);
+    const int ys = max(tl.y0 - 1, in), ye = min(tl.y0 + kTileH + 1, L.h - in);
+    unsigned long long* mk = mask + (size_t)b * g.total_words + L.word_base + (tl.x0 >> 6);
+    uint8_t* sc = score + (size_t)b * atlas_bytes + (size_t)(L.y + tl.y0) * aw + L.x + tl.x0;
+    const bool empty = xs >= xe || ys >= ye || (!DENSE && !level_ok);
+    if (empty && !DENSE) {
+        if (tid < kTileH && tl.y0 + tid < L.h) mk[(size_t)(tl.y0 + tid) * L.words_per_row] = 0ull;
+        return;
     }
+    // stage the tile with a 4-pixel halo, aligned dwords (levels sit at least 32 pixels inside the atlas)
+    const int ox = L.x + tl.x0 - 4, oy = L.y + tl.y0 - 4;
+    const int abase = ox & ~3, off = ox & 3;
+    const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
+    for (int i = tid; i < kFRows * (kFPitch / 4); i += 256) {
+        const int r = i / (kFPitch / 4), c = i - r * (kFPitch / 4);
+        const int ax = min(abase + 4 * c, aw - 4), ay = min(oy + r, g.atlas_h - 1);
+        t32[i] = *(const unsigned*)(fb + (size_t)ay * aw + ax);
+    }
+    for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
+    if (tid == 0) q_count = 0;
     __syncthreads();
-    const int lx = threadIdx.x & 63;
-    const int x = tl.x0 + lx;
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    // phase 1: rows ys..ye of the scored rectangle, kSW columns from x0-1 each
+    const int n1 = empty ? 0 : (ye - ys) * kSW;
+    for (int base = 0; base < n1; base += 256) {
+        const int idx = min(base + tid, n1 - 1);
+        const int r = idx / kSW, c = idx - r * kSW;
+        const int x = tl.x0 - 1 + c, y = ys + r;
+        const bool valid = base + tid < n1 && x >= xs && x < xe;
+        const unsigned long long vm = __ballot(valid);
+        if (vm == 0ull) continue;
+        const uint8_t* ctr = t + (y - tl.y0 + 4) * kFPitch + c + 3 + off;
+        const int v = ctr[0];
+        const int hi = v + threshold, lw = v - threshold;
+        // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12): a pixel without two
+        // adjacent compass points on the same side of the threshold band cannot be a corner
+        const int p0 = ctr[3 * kFPitch], p4 = ctr[3], p8 = ctr[-3 * kFPitch], p12 = ctr[-3];
+        const unsigned long long b0 = __ballot(p0 > hi), b4 = __ballot(p4 > hi), b8 = __ballot(p8 > hi),
+                                 b12 = __ballot(p12 > hi);
+        const unsigned long long d0 = __ballot(p0 < lw), d4 = __ballot(p4 < lw), d8 = __ballot(p8 < lw),
+                                 d12 = __ballot(p12 < lw);
+        const unsigned long long pass =
+            (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) & vm;
+        if (pass == 0ull) continue;
+        int qb = 0;
+        if (lane == 0) qb = atomicAdd(&q_count, __popcll(pass));
+        qb = __builtin_amdgcn_readfirstlane(qb);
+        if ((pass >> lane) & 1ull)
+            queue[qb + __popcll(pass & ((1ull << lane) - 1ull))] = (unsigned short)((y - tl.y0 + 1) * kSW + c);
+    }
+    __syncthreads();
+    // phase 2: cornerScore of the queued pixels: max(threshold, best arc-of-9 minimum of |v - p|) - 1
+    const int nq = q_count;
+    for (int q = tid; q < nq; q += 256) {
+        const int pos = queue[q];
+        const int r = pos / kSW, c = pos - r * kSW;
+        const uint8_t* ctr = t + (r + 3) * kFPitch + c + 3 + off;
+        const int v = ctr[0];
+        int d[16], m2[16], m4[16], x2[16], x4[16];
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int ly = (threadIdx.x >> 6) + rr * 4;
-        const int y = tl.y0 + ly;
-        if (x >= L.w || y >= L.h) continue;
-        int s = 0;
-        if (x >= 3 && x < L.w - 3 && y >= 3 && y < L.h - 3) {
-            const int v = t[ly + 3][lx + 3];
-            const int lo = v - threshold, hi = v + threshold;
-            int p[16];
-            unsigned dark = 0, bright = 0;
+        for (int k = 0; k < 16; k++) d[k] = v - (int)ctr[dy[k] * kFPitch + dx[k]];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                p[k] = t[ly + 3 + dy[k]][lx + 3 + dx[k]];
-                dark |= (unsigned)(p[k] < lo) << k;
-                bright |= (unsigned)(p[k] > hi) << k;
-            }
-            if (has_arc9(dark) || has_arc9(bright)) {
-                // score = max(threshold, best over the 16 arcs of 9 of min(v-p), same for p-v) - 1
-                int d[16], m2[16], m4[16], x2[16], x4[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) d[k] = v - p[k];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    m2[k] = min(d[k], d[(k + 1) & 15]);
-                    x2[k] = max(d[k], d[(k + 1) & 15]);
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    m4[k] = min(m2[k], m2[(k + 2) & 15]);
-                    x4[k] = max(x2[k], x2[(k + 2) & 15]);
-                }
-                int best = threshold;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    int mn = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
-                    int mx = max(max(x4[k], x4[(k + 4) & 15]), d[(k + 8) & 15]);
-                    best = max(best, max(mn, -mx));
-                }
-                s = best - 1;
-            }
+        for (int k = 0; k < 16; k++) {
+            m2[k] = min(d[k], d[(k + 1) & 15]);
+            x2[k] = max(d[k], d[(k + 1) & 15]);
         }
-        score[(size_t)b * atlas_bytes + (size_t)(L.y + y) * aw + L.x + x] = (uint8_t)s;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            m4[k] = min(m2[k], m2[(k + 2) & 15]);
+            x4[k] = max(x2[k], x2[(k + 2) & 15]);
+        }
+        int best = threshold;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int mn = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
+            const int mx = max(max(x4[k], x4[(k + 4) & 15]), d[(k + 8) & 15]);
+            best = max(best, max(mn, -mx));
+        }
+        if (best > threshold) st[pos] = (uint8_t)(best - 1);  // an arc of nine clears the band <=> a corner
     }
-}
-
-// K4a: 3x3 strict non-max suppression + cv::KeyPointsFilter::runByImageBorder as one bit per level pixel
-// (one 64-bit ballot word per wavefront, rows padded to whole words).
-__global__ __launch_bounds__(256) void k_nms_mask(const uint8_t* __restrict__ score, unsigned long long* __restrict__ mask,
-                                                  size_t atlas_bytes, Geom g) {
-    const int word = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    if (word >= g.total_words) return;
-    int l = 0;
-    while (l + 1 < g.nlevels && word >= g.L[l + 1].word_base) l++;
-    const LevelInfo L = g.L[l];
-    const int r = word - L.word_base;
-    const int y = r / L.words_per_row;
-    const int x = (r - y * L.words_per_row) * 64 + lane;
-    const int lo = max(3, g.edge);
-    bool kp = false;
-    const bool level_ok = g.edge <= 0 || (L.w > 2 * g.edge && L.h > 2 * g.edge);
-    if (level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo) {
-        const int aw = g.atlas_w;
-        const uint8_t* s = score + (size_t)b * atlas_bytes + (size_t)(L.y + y) * aw + L.x + x;
+    __syncthreads();
+    // phase 3: suppression, border rule, one mask word per tile row
+    for (int r = wv; r < kTileH; r += 4) {
+        const int y = tl.y0 + r, x = tl.x0 + lane;
+        if (y >= L.h) break;
+        const uint8_t* s = st + (r + 1) * kSW + lane + 1;
         const int c = s[0];
-        if (c)
-            kp = c > s[1] && c > s[-1] && c > s[-aw - 1] && c > s[-aw] && c > s[-aw + 1] && c > s[aw - 1] &&
-                 c > s[aw] && c > s[aw + 1];
+        bool kp = false;
+        if (c && level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo)
+            kp = c > s[1] && c > s[-1] && c > s[-kSW - 1] && c > s[-kSW] && c > s[-kSW + 1] && c > s[kSW - 1] &&
+                 c > s[kSW] && c > s[kSW + 1];
+        const unsigned long long w = __ballot(kp);
+        if (lane == 0) mk[(size_t)y * L.words_per_row] = w;
+        if (DENSE) {
+            if (x < L.w) sc[(size_t)r * aw + lane] = (uint8_t)c;
+        } else if (kp)
+            sc[(size_t)r * aw + lane] = (uint8_t)c;
     }
-    const unsigned long long m = __ballot(kp);
-    if (lane == 0) mask[(size_t)b * g.total_words + word] = m;
 }
 
 // K4b: ordered emission. One workgroup per frame walks the mask words in level-major raster order and appends the
