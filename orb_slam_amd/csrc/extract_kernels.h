@@ -373,9 +373,28 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 struct UMax { int v[16]; };
 
+// Sum over the wavefront, returned as a wave-uniform value (row reduction with DPP, rows combined by readlane).
+__device__ __forceinline__ int wave_sum_uniform(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// Four bytes from any address; the compiler picks the widest load the target allows for byte alignment.
+__device__ __forceinline__ unsigned load_u32_any(const uint8_t* p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
 // K5/K6: Harris response (cv::ORB HarrisResponses, 7x7 block, k = 0.04) and intensity-centroid angle
 // (cv::ORB ICAngles, radius 15) of one candidate per wavefront.  Candidates whose FAST score is below the level's
 // retainBest(2*quota) value are skipped: cv::ORB has dropped them before it computes either quantity.
+// Harris: lane = one pixel of the block, three 4-byte row loads.  Angle: lane = half a patch row, four 4-byte loads,
+// byte sums and |u|-weighted byte sums by dot products (all integer, so the summation order does not matter).
 __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
                                                       Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
                                                       const int* __restrict__ thresholds, UMax umax,
@@ -384,6 +403,30 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
     const int b = blockIdx.y;
     const int total = min(totals[b], cap);
     const int aw = g.atlas_w;
+    unsigned long long umax4 = 0ull;  // sixteen 4-bit row half-widths
+#pragma unroll
+    for (int k = 0; k < 16; k++) umax4 |= (unsigned long long)(umax.v[k] & 15) << (4 * k);
+    // per-lane constants of the angle part
+    const int v = (lane >> 1) - 15;
+    const bool right = lane & 1;
+    const int d = lane < 62 ? (int)((umax4 >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
+    const int row_ofs = v * aw + (right ? 1 : -15);
+    unsigned msk[4], wgt[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (right) {  // byte i of the 16 holds u = i + 1; keep u <= d
+            const int keep = min(max(d - 4 * j, 0), 4);
+            msk[j] = keep == 0 ? 0u : 0xffffffffu >> (8 * (4 - keep));
+            wgt[j] = 0x04030201u + 0x04040404u * j;
+        } else {      // byte i holds u = i - 15; keep -u <= d
+            const int skip = min(max(15 - d - 4 * j, 0), 4);
+            msk[j] = skip == 4 ? 0u : 0xffffffffu << (8 * skip);
+            wgt[j] = 0x0c0d0e0fu - 0x04040404u * j;
+        }
+        if (d < 0) msk[j] = 0u;
+    }
+    const int hi = lane / 7 - 3, hj = lane - (lane / 7) * 7 - 3;
+    const int h_ofs = lane < 49 ? hi * aw + hj - 1 : -1;
     // grid-stride over the frame's candidates: gridDim.x * 4 wavefronts per frame
     for (int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 6); idx < total; idx += gridDim.x * 4) {
         Cand* cp = cand + (size_t)b * cap + idx;
@@ -391,37 +434,35 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
         if ((int)c.score < thresholds[b * kMaxLevels + c.level]) continue;
         const LevelInfo L = g.L[c.level];
         const uint8_t* center = atlas + (size_t)b * atlas_bytes + (size_t)(L.y + c.y) * aw + L.x + c.x;
+        const uint8_t* hp = center + h_ofs;
+        const unsigned r0 = load_u32_any(hp - aw), r1 = load_u32_any(hp), r2 = load_u32_any(hp + aw);
+        const uint8_t* ip = center + row_ofs;
+        unsigned q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = load_u32_any(ip + 4 * j);
         int ha = 0, hb = 0, hc = 0;
         if (lane < 49) {
-            const int i = lane / 7 - 3, j = lane - (lane / 7) * 7 - 3;
-            const uint8_t* p = center + i * aw + j;
-            const int Ix = (p[1] - p[-1]) * 2 + (p[-aw + 1] - p[-aw - 1]) + (p[aw + 1] - p[aw - 1]);
-            const int Iy = (p[aw] - p[-aw]) * 2 + (p[aw - 1] - p[-aw - 1]) + (p[aw + 1] - p[-aw + 1]);
+            const int a0 = r0 & 255, a1 = (r0 >> 8) & 255, a2 = (r0 >> 16) & 255;
+            const int b0 = r1 & 255, b2 = (r1 >> 16) & 255;
+            const int c0 = r2 & 255, c1 = (r2 >> 8) & 255, c2 = (r2 >> 16) & 255;
+            const int Ix = (b2 - b0) * 2 + (a2 - a0) + (c2 - c0);
+            const int Iy = (c1 - a1) * 2 + (c0 - a0) + (c2 - a2);
             ha = Ix * Ix;
             hb = Iy * Iy;
             hc = Ix * Iy;
         }
-        ha = wave_sum_i32(ha);
-        hb = wave_sum_i32(hb);
-        hc = wave_sum_i32(hc);
-        int m10 = 0, m01 = 0;
-        if (lane < 31) {
-            const int v = lane - 15;
-            const int d = umax.v[v < 0 ? -v : v];
-            const uint8_t* row = center + v * aw;
-            int s = 0, su = 0;
-            for (int u = -d; u <= d; u++) {
-                const int val = row[u];
-                s += val;
-                su += u * val;
-            }
-            m10 = su;
-            m01 = v * s;
+        unsigned ssum = 0, wsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned m = q[j] & msk[j];
+            ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
+            wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
         }
-        m10 = wave_sum_i32(m10);
-        m01 = wave_sum_i32(m01);
+        const int sha = wave_sum_uniform(ha), shb = wave_sum_uniform(hb), shc = wave_sum_uniform(hc);
+        const int m10 = wave_sum_uniform(right ? (int)wsum : -(int)wsum);
+        const int m01 = wave_sum_uniform(v * (int)ssum);
         if (lane == 0) {
-            const float fa = (float)ha, fb = (float)hb, fc = (float)hc;
+            const float fa = (float)sha, fb = (float)shb, fc = (float)shc;
             const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
             cp->harris = resp;
             cp->angle = fast_atan2_deg((float)m01, (float)m10);
