@@ -737,6 +737,297 @@ __global__ __launch_bounds__(64) void k_resolve_lists(ProjArgs A) {
     if (lane == 0 && A.n_matches) *A.n_matches = cnt;
 }
 
+// ---- batched frame-to-frame matcher: records -> sorted window lists -> speculative resolve -------------------------
+
+// One feature of a frame in the order of the CSR bucket grid, with everything the window test reads.
+struct ItemRec {
+    float x, y;
+    uint32_t idx_oct;   // feature index | (octave saturated to int8) << 24
+    uint16_t cx, cy;    // grid cell
+};
+
+// K10r: CSR-ordered feature records of the frame of every pair (one thread per grid cell).
+__global__ __launch_bounds__(256) void k_item_records(ProjArgs A, ItemRec* __restrict__ recs) {
+    const int pair = blockIdx.y;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    const int ncells = A.g.grid_cols * A.g.grid_rows;
+    if (cell >= ncells) return;
+    const int fi = A.frame_index ? A.frame_index[pair] : 0;
+    const int32_t* cs = A.cell_start + (size_t)fi * A.cell_stride;
+    const int32_t* ci = A.cell_items + (size_t)fi * A.kp_stride;
+    const orbx_keypoint* kps = A.kps + (size_t)fi * A.kp_stride;
+    ItemRec* out = recs + (size_t)pair * A.kp_stride;
+    const int i0 = cs[cell], i1 = cs[cell + 1];
+    for (int i = i0; i < i1; i++) {
+        const int idx = ci[i];
+        const orbx_keypoint k = kps[idx];
+        ItemRec r;
+        r.x = k.x;
+        r.y = k.y;
+        r.idx_oct = (uint32_t)idx | ((uint32_t)(min(max(k.octave, -128), 127) & 0xff) << 24);
+        r.cx = (uint16_t)(cell / A.g.grid_rows);
+        r.cy = (uint16_t)(cell % A.g.grid_rows);
+        out[i] = r;
+    }
+}
+
+__device__ __forceinline__ bool in_window_rec(const ItemRec& r, const Window& W) {
+    const int oct = (int)(int8_t)(r.idx_oct >> 24);
+    if (W.min_only) {
+        if (oct < W.min_level) return false;
+        return fabsf(r.x - (float)r.cx) < W.radius_scaled && fabsf(r.y - (float)r.cy) < W.radius_scaled;
+    }
+    if (oct < W.min_level || oct > W.max_level) return false;
+    return fabsf(r.x - W.px) < W.radius_scaled && fabsf(r.y - W.py) < W.radius_scaled;
+}
+
+// Inclusive prefix sum over the 16 lanes of a DPP row.
+__device__ __forceinline__ int row16_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// K10s: window gather for the batched frame-to-frame matcher, 16 lanes per reference point.  The cells of one grid
+// column of a window are adjacent in the CSR order, so a window is a handful of contiguous record runs; the lanes
+// take the records of all runs side by side, test them, and append the accepted ones (with their Hamming distance)
+// in scan order.  The list is then sorted by (distance, LAST scan position first) - the order in which the
+// reference's `<=` minimum search (orb_matcher.cpp:222) would prefer them - so the resolve step only ever needs
+// the first entry that is still free.
+// win_n[ref] = -1: point skipped; > kWinK: list too long, the resolve step scans that window itself.
+__global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec* __restrict__ recs_all) {
+    __shared__ int2 s_ent[16][kWinK];
+    __shared__ int s_incl[16][16];
+    __shared__ int s_first[16][16];
+    const int gl = threadIdx.x & 15;
+    const int grp = threadIdx.x >> 4;
+    const int sub = (threadIdx.x >> 4) & 3;  // group inside the wavefront
+    const ItemRec* recs = recs_all + (size_t)blockIdx.y * A.kp_stride;
+    resolve_views(A, blockIdx.y);
+    const int ref_idx = blockIdx.x * 16 + grp;
+    if (ref_idx >= A.n_ref) return;
+    const orbx_grid& g = A.g;
+    Window W;
+    if (!window_of<0>(A, ref_idx, W)) {
+        if (gl == 0) A.win_n[ref_idx] = -1;
+        return;
+    }
+    const uint4* rdp = (const uint4*)(A.ref_desc + (size_t)ref_idx * 32);
+    const uint4 ra = rdp[0], rb = rdp[1];
+    const int ncols = W.ncells / W.ncy;
+    int list_n = 0;
+    for (int cb = 0; cb < ncols && list_n <= kWinK; cb += 16) {
+        int start = 0, len = 0;
+        if (cb + gl < ncols) {
+            const int c0 = (W.left + cb + gl) * g.grid_rows + W.up;
+            start = A.cell_start[c0];
+            len = A.cell_start[c0 + W.ncy] - start;
+        }
+        const int incl = row16_scan(len);
+        const int total = __shfl(incl, 15, 16);
+        s_incl[grp][gl] = incl;
+        s_first[grp][gl] = start - (incl - len);  // record of item t of this run = first + t
+        wave_lds_fence();
+        for (int tb = 0; tb < total && list_n <= kWinK; tb += 16) {
+            const int t = tb + gl;
+            bool ok = false;
+            ItemRec r;
+            if (t < total) {
+                int run = 0;
+                while (t >= s_incl[grp][run]) run++;
+                r = recs[s_first[grp][run] + t];
+                ok = in_window_rec(r, W);
+            }
+            const unsigned gm = (unsigned)(__ballot(ok) >> (16 * sub)) & 0xffffu;
+            const int pos = list_n + __popc(gm & ((1u << gl) - 1u));
+            if (ok && pos < kWinK) {
+                const int idx = (int)(r.idx_oct & 0xffffffu);
+                const uint4* dp = (const uint4*)(A.desc + (size_t)idx * 32);
+                const uint4 da = dp[0], db = dp[1];
+                const int d = __popc(ra.x ^ da.x) + __popc(ra.y ^ da.y) + __popc(ra.z ^ da.z) + __popc(ra.w ^ da.w) +
+                              __popc(rb.x ^ db.x) + __popc(rb.y ^ db.y) + __popc(rb.z ^ db.z) + __popc(rb.w ^ db.w);
+                s_ent[grp][pos] = make_int2(idx, d);
+            }
+            list_n += __popc(gm);
+        }
+        wave_lds_fence();
+    }
+    if (gl == 0) A.win_n[ref_idx] = list_n;
+    if (list_n > kWinK) return;
+    wave_lds_fence();
+    // rank sort: key = distance << 8 | (63 - scan position); keys are distinct
+    int2* list = A.win_list + (size_t)ref_idx * kWinK;
+    for (int i = gl; i < list_n; i += 16) {
+        const int2 e = s_ent[grp][i];
+        const unsigned key = ((unsigned)e.y << 8) | (unsigned)(63 - i);
+        int rank = 0;
+        for (int j = 0; j < list_n; j++) {
+            const unsigned kj = ((unsigned)s_ent[grp][j].y << 8) | (unsigned)(63 - j);
+            rank += kj < key;
+        }
+        list[rank] = e;
+    }
+}
+
+// K10t: resolve of the batched frame-to-frame matcher, one wavefront per pair, 64 reference points at a time.
+// The reference visits its points in order and gives each the best feature not taken by an earlier point
+// (orb_matcher.cpp:216-236).  Here every lane holds one point and proposes the first free entry of its sorted list;
+// the lanes below the first lane whose proposal collides with a lower lane's have pairwise distinct proposals made
+// from the same state, which is exactly what the sequential walk gives them, so they commit together; the others
+// propose again.  A point without a free entry within the distance bound stays without a match whatever the
+// earlier points do (taken features only accumulate).  Points with an over-long window split the block: they are
+// resolved on their own, by a scan of the grid with all 64 lanes, when every point before them is done.
+constexpr int kStage = 8;  // list entries per point staged in LDS; deeper ones are read from memory
+__global__ __launch_bounds__(64) void k_resolve_sorted(ProjArgs A) {
+    extern __shared__ int32_t s_mem[];
+    __shared__ int32_t s_hist[30];
+    __shared__ int2 s_stage[64 * kStage];
+    const int lane = threadIdx.x;
+    const int pair = blockIdx.x;
+    const int cap = (int)A.kp_stride;
+    int32_t* s_matched = s_mem;            // [cap]
+    int32_t* s_dists = s_mem + cap;        // [cap]
+    int32_t* s_claim = s_mem + 2 * cap;    // [cap]
+    int32_t* s_push = s_mem + 3 * cap;     // [2 * cap]
+    resolve_views(A, pair);
+    for (int i = lane; i < cap; i += 64) {
+        s_matched[i] = -1;
+        s_dists[i] = -1;
+        s_claim[i] = 0x7fffffff;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    __syncthreads();
+    int n_push = 0;
+    // staged entries of the block: 64 points x kStage entries = 4 x uint4 per lane
+    auto stage_ptr = [&](int base, int j) {
+        const int q = lane + 64 * j;  // uint4 units: 2 entries each, kStage / 2 per point
+        const int ref = min(base + q / (kStage / 2), max(A.n_ref - 1, 0));
+        return (const uint4*)(A.win_list + (size_t)ref * kWinK) + (q % (kStage / 2));
+    };
+    uint4 pf[4];
+    int pf_n = -1;
+    if (A.n_ref > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) pf[j] = *stage_ptr(0, j);
+        if (lane < A.n_ref) pf_n = A.win_n[lane];
+    }
+    for (int base = 0; base < A.n_ref; base += 64) {
+        const int n = pf_n;
+#pragma unroll
+        for (int j = 0; j < 4; j++) ((uint4*)s_stage)[lane + 64 * j] = pf[j];
+        if (base + 64 < A.n_ref) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) pf[j] = *stage_ptr(base + 64, j);
+            pf_n = base + 64 + lane < A.n_ref ? A.win_n[base + 64 + lane] : -1;
+        }
+        wave_lds_fence();
+        const int ref_idx = base + lane;
+        const int2* my_list = A.win_list + (size_t)min(ref_idx, max(A.n_ref - 1, 0)) * kWinK;
+        int cursor = 0;
+        bool done = !(n > 0);
+        unsigned long long ovm = __ballot(n > kWinK);
+        while (true) {
+            const int limit = ovm ? __ffsll((long long)ovm) - 1 : 64;
+            while (true) {
+                bool prop = false;
+                int f = 0, d = 0;
+                if (lane < limit && !done) {
+                    int2 e = make_int2(0, 0);
+                    while (cursor < n) {
+                        e = cursor < kStage ? s_stage[lane * kStage + cursor] : my_list[cursor];
+                        if (!(s_matched[e.x] > 0)) break;
+                        cursor++;
+                    }
+                    if (cursor >= n || e.y > 100) done = true;
+                    else { prop = true; f = e.x; d = e.y; }
+                }
+                if (__ballot(prop) == 0ull) break;
+                if (prop) atomicMin(&s_claim[f], lane);
+                wave_lds_fence();
+                const bool conflict = prop && s_claim[f] != lane;
+                const unsigned long long cm = __ballot(conflict);
+                const int rstar = cm ? __ffsll((long long)cm) - 1 : 64;
+                const bool commit = prop && lane < rstar;
+                const unsigned long long km = __ballot(commit);
+                wave_lds_fence();
+                if (prop) s_claim[f] = 0x7fffffff;
+                if (commit) {
+                    const int pos = n_push + __popcll(km & ((1ull << lane) - 1ull));
+                    s_matched[f] = ref_idx;
+                    s_dists[f] = d;
+                    s_push[2 * pos] = ref_idx;
+                    s_push[2 * pos + 1] = f;
+                    done = true;
+                }
+                n_push += __popcll(km);
+                wave_lds_fence();
+            }
+            if (limit == 64) break;
+            const long long r = best_in_window_scan(A, base + limit, s_matched, lane);
+            if (r >= 0 && (int)(r >> 32) <= 100) {
+                const int id = (int)(r & 0xffffffff);
+                if (lane == 0) {
+                    s_matched[id] = base + limit;
+                    s_dists[id] = (int)(r >> 32);
+                    s_push[2 * n_push] = base + limit;
+                    s_push[2 * n_push + 1] = id;
+                }
+                n_push++;
+            }
+            if (lane == limit) done = true;
+            ovm &= ovm - 1ull;
+            wave_lds_fence();
+        }
+    }
+    __syncthreads();
+    if (A.check_orientation) {
+        const float factor = 1.0f / 30;
+        for (int i = lane; i < n_push; i += 64) {
+            float rot = A.ref_kps[s_push[2 * i]].angle - A.kps[s_push[2 * i + 1]].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin < 0 || bin >= 30) bin = -1;
+            else atomicAdd(&s_hist[bin], 1);
+            s_push[2 * i] = bin;
+        }
+        __syncthreads();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = lane; i < n_push; i += 64) {
+            const int bin = s_push[2 * i];
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) s_matched[s_push[2 * i + 1]] = 0;
+        }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int i = lane; i < cap; i += 64) {
+        const int m = i < A.n ? s_matched[i] : -1;
+        A.matched[i] = m;
+        A.dists[i] = s_dists[i];
+        cnt += m > 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0 && A.n_matches) *A.n_matches = cnt;
+}
+
 }  // namespace
 
 struct orbx_matcher {
@@ -749,7 +1040,8 @@ struct orbx_matcher {
     DevBuf<orbx_keypoint> d_kp, d_refkp;
     DevBuf<int32_t> d_win_n, d_win_over;
     DevBuf<int2> d_win_list;
-    size_t fast_lds_attr = 0;
+    DevBuf<uint8_t> d_recs;
+    size_t fast_lds_attr = 0, lists_lds_attr = 0;
     std::vector<unsigned long long> h_best;
 };
 
@@ -789,7 +1081,7 @@ void orbx_matcher_destroy(orbx_matcher* h) {
     h->d_q.release(); h->d_t.release(); h->d_flags.release(); h->d_best.release(); h->d_idx.release();
     h->d_dist.release(); h->d_ints.release(); h->d_cells.release(); h->d_items.release(); h->d_pushes.release();
     h->d_f0.release(); h->d_f1.release(); h->d_f2.release(); h->d_kp.release(); h->d_refkp.release();
-    h->d_win_n.release(); h->d_win_over.release(); h->d_win_list.release();
+    h->d_win_n.release(); h->d_win_over.release(); h->d_win_list.release(); h->d_recs.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1076,17 +1368,30 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     A.win_list = h->d_win_list.p;
     A.win_overflow = h->d_win_over.p;
     A.need_slow = h->d_win_over.p;
-    hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A);
-    const size_t fast_lds = sizeof(int32_t) * 4 * (size_t)kp_capacity;
+    if (kp_capacity > 6144) {
+        // the speculative resolve keeps five words per feature in LDS; beyond that use the sequential one
+        hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A);
+        const size_t lds = sizeof(int32_t) * 4 * (size_t)kp_capacity;
+        if (lds > 48 * 1024 && lds > h->lists_lds_attr) {
+            ORBX_HIP(hipFuncSetAttribute((const void*)k_resolve_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->lists_lds_attr = lds;
+        }
+        hipLaunchKernelGGL(k_resolve_lists, dim3(n_pairs), dim3(64), lds, s, A);
+        ORBX_HIP(hipGetLastError());
+        return ORBX_OK;
+    }
+    ORBX_TRY(h->d_recs.ensure((size_t)kp_capacity * n_pairs * sizeof(ItemRec)));
+    ItemRec* recs = (ItemRec*)h->d_recs.p;
+    const int ncells = g->grid_cols * g->grid_rows;
+    if (g->grid_cols > 65535 || g->grid_rows > 65535 || kp_capacity >= (1 << 24)) return ORBX_UNSUPPORTED;
+    hipLaunchKernelGGL(k_item_records, dim3(div_up(ncells, 256), n_pairs), dim3(256), 0, s, A, recs);
+    hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A, recs);
+    const size_t fast_lds = sizeof(int32_t) * 5 * (size_t)kp_capacity;
     if (fast_lds > 48 * 1024 && fast_lds > h->fast_lds_attr) {
-        ORBX_HIP(hipFuncSetAttribute((const void*)k_resolve_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
+        ORBX_HIP(hipFuncSetAttribute((const void*)k_resolve_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
         h->fast_lds_attr = fast_lds;
     }
-    hipLaunchKernelGGL(k_resolve_lists, dim3(n_pairs), dim3(64), fast_lds, s, A);
-    // pairs flagged by the lean kernel (a window longer than its lists hold) are redone by the general one
-    A.win_n = nullptr;
-    A.win_list = nullptr;
-    hipLaunchKernelGGL(k_projection_match<0>, dim3(n_pairs), dim3(64), sizeof(int32_t) * (size_t)kp_capacity, s, A);
+    hipLaunchKernelGGL(k_resolve_sorted, dim3(n_pairs), dim3(64), fast_lds, s, A);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }
