@@ -388,9 +388,12 @@ def test_frame_model_batch_and_batched_projection(oracle, test_images):
     kp_ptr, desc_ptr, cnt_ptr, kcap = ex.device_results()
     cs_ptr, ci_ptr = ex.device_grid()
     assert kcap == cap
-    for radius, orient in ((15.0, True), (40.0, False)):
+    # radius 40 and 90 make windows longer than the pre-gathered lists hold; level modes 1 and 2 are the
+    # "in front" / "behind" window rules
+    for radius, orient, level_mode in ((15.0, True, 0), (40.0, False, 0), (25.0, True, 1), (25.0, False, 2),
+                                       (90.0, True, 0)):
         mt.match_projection_frame_batch(grid, P, d_fi.data_ptr(), d_ri.data_ptr(), kp_ptr, desc_ptr, cnt_ptr, cap,
-                                        cs_ptr, ci_ptr, 0, d_proj.data_ptr(), 0, sf, 0, radius, orient,
+                                        cs_ptr, ci_ptr, 0, d_proj.data_ptr(), 0, sf, level_mode, radius, orient,
                                         d_matched.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr())
         torch.cuda.synchronize()
         hm, hd, hn = d_matched.cpu().numpy(), d_dist.cpu().numpy(), d_nm.cpu().numpy()
@@ -398,12 +401,13 @@ def test_frame_model_batch_and_batched_projection(oracle, test_images):
             fk, fd, start, items = ora[f]
             rk, rd = ora[r][0], ora[r][1]
             om = oracle.match_projection_frame(og, start, items, fk, fd, rk, np.ones(len(rk), np.uint8),
-                                               proj[i, :len(rk)], np.ones(len(rk), np.float32), rd, sf, 0, radius,
-                                               orient)
+                                               proj[i, :len(rk)], np.ones(len(rk), np.float32), rd, sf, level_mode,
+                                               radius, orient)
             got_q = np.nonzero(hm[i, :len(fk)] > 0)[0]
-            assert hn[i] == len(om) == len(got_q), (i, radius)
+            assert hn[i] == len(om) == len(got_q), (i, radius, level_mode)
             assert np.array_equal(got_q, om["query"]) and np.array_equal(hm[i, got_q], om["train"])
             assert np.array_equal(hd[i, got_q].astype(np.float32), om["distance"])
-        assert hn.min() > 100
+        if level_mode != 1:  # the 4-argument window test compares pixels with cell indices: it accepts nothing here
+            assert hn.min() > 100
     ex.close()
     mt.close()
