@@ -169,6 +169,7 @@ struct ProjArgs {
     // pre-gathered search windows (K10a), or NULL: the resolve kernel gathers by itself
     int32_t* win_n;             // [pairs][pair_stride]
     int2* win_list;             // [pairs][pair_stride][kWinK] (feature index, Hamming distance)
+    int win_stride;             // entries per reference point in win_list
     int32_t* win_overflow;      // [pairs]
     int32_t* need_slow;         // [pairs] or NULL: K10c sets it for a pair with an over-long window; K10b then runs
                                 // only for flagged pairs
@@ -232,7 +233,7 @@ __device__ __forceinline__ void resolve_views(ProjArgs& A, int pair) {
     if (A.need_slow) A.need_slow += pair;
     if (A.win_n) {
         A.win_n += po;
-        A.win_list += po * kWinK;
+        A.win_list += po * (size_t)A.win_stride;
         A.win_overflow += pair;
     }
     A.n = min(A.n, kMaxFeatures);
@@ -740,6 +741,8 @@ __global__ __launch_bounds__(64) void k_resolve_lists(ProjArgs A) {
 // ---- batched frame-to-frame matcher: records -> sorted window lists -> speculative resolve -------------------------
 
 // One feature of a frame in the order of the CSR bucket grid, with everything the window test reads.
+constexpr int kSortK = 128;  // entries per reference point in the sorted window lists
+
 struct ItemRec {
     float x, y;
     uint32_t idx_oct;   // feature index | (octave saturated to int8) << 24
@@ -802,9 +805,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // in scan order.  The list is then sorted by (distance, LAST scan position first) - the order in which the
 // reference's `<=` minimum search (orb_matcher.cpp:222) would prefer them - so the resolve step only ever needs
 // the first entry that is still free.
-// win_n[ref] = -1: point skipped; > kWinK: list too long, the resolve step scans that window itself.
+// win_n[ref] = -1: point skipped; > kSortK: list too long, the resolve step scans that window itself.
 __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec* __restrict__ recs_all) {
-    __shared__ int2 s_ent[16][kWinK];
+    __shared__ int2 s_ent[16][kSortK];
     __shared__ int s_incl[16][16];
     __shared__ int s_first[16][16];
     const int gl = threadIdx.x & 15;
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
     const uint4 ra = rdp[0], rb = rdp[1];
     const int ncols = W.ncells / W.ncy;
     int list_n = 0;
-    for (int cb = 0; cb < ncols && list_n <= kWinK; cb += 16) {
+    for (int cb = 0; cb < ncols && list_n <= kSortK; cb += 16) {
         int start = 0, len = 0;
         if (cb + gl < ncols) {
             const int c0 = (W.left + cb + gl) * g.grid_rows + W.up;
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
         s_incl[grp][gl] = incl;
         s_first[grp][gl] = start - (incl - len);  // record of item t of this run = first + t
         wave_lds_fence();
-        for (int tb = 0; tb < total && list_n <= kWinK; tb += 16) {
+        for (int tb = 0; tb < total && list_n <= kSortK; tb += 16) {
             const int t = tb + gl;
             bool ok = false;
             ItemRec r;
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
             }
             const unsigned gm = (unsigned)(__ballot(ok) >> (16 * sub)) & 0xffffu;
             const int pos = list_n + __popc(gm & ((1u << gl) - 1u));
-            if (ok && pos < kWinK) {
+            if (ok && pos < kSortK) {
                 const int idx = (int)(r.idx_oct & 0xffffffu);
                 const uint4* dp = (const uint4*)(A.desc + (size_t)idx * 32);
                 const uint4 da = dp[0], db = dp[1];
@@ -861,16 +864,16 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
         wave_lds_fence();
     }
     if (gl == 0) A.win_n[ref_idx] = list_n;
-    if (list_n > kWinK) return;
+    if (list_n > kSortK) return;
     wave_lds_fence();
-    // rank sort: key = distance << 8 | (63 - scan position); keys are distinct
-    int2* list = A.win_list + (size_t)ref_idx * kWinK;
+    // rank sort: key = distance << 8 | (255 - scan position); keys are distinct
+    int2* list = A.win_list + (size_t)ref_idx * kSortK;
     for (int i = gl; i < list_n; i += 16) {
         const int2 e = s_ent[grp][i];
-        const unsigned key = ((unsigned)e.y << 8) | (unsigned)(63 - i);
+        const unsigned key = ((unsigned)e.y << 8) | (unsigned)(255 - i);
         int rank = 0;
         for (int j = 0; j < list_n; j++) {
-            const unsigned kj = ((unsigned)s_ent[grp][j].y << 8) | (unsigned)(63 - j);
+            const unsigned kj = ((unsigned)s_ent[grp][j].y << 8) | (unsigned)(255 - j);
             rank += kj < key;
         }
         list[rank] = e;
@@ -885,11 +888,10 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
 // propose again.  A point without a free entry within the distance bound stays without a match whatever the
 // earlier points do (taken features only accumulate).  Points with an over-long window split the block: they are
 // resolved on their own, by a scan of the grid with all 64 lanes, when every point before them is done.
-constexpr int kStage = 8;  // list entries per point staged in LDS; deeper ones are read from memory
+constexpr int kHead = 8;  // list entries per point held in registers; deeper ones are read from memory
 __global__ __launch_bounds__(64) void k_resolve_sorted(ProjArgs A) {
     extern __shared__ int32_t s_mem[];
     __shared__ int32_t s_hist[30];
-    __shared__ int2 s_stage[64 * kStage];
     const int lane = threadIdx.x;
     const int pair = blockIdx.x;
     const int cap = (int)A.kp_stride;
@@ -906,48 +908,62 @@ __global__ __launch_bounds__(64) void k_resolve_sorted(ProjArgs A) {
     if (lane < 30) s_hist[lane] = 0;
     __syncthreads();
     int n_push = 0;
-    // staged entries of the block: 64 points x kStage entries = 4 x uint4 per lane
-    auto stage_ptr = [&](int base, int j) {
-        const int q = lane + 64 * j;  // uint4 units: 2 entries each, kStage / 2 per point
-        const int ref = min(base + q / (kStage / 2), max(A.n_ref - 1, 0));
-        return (const uint4*)(A.win_list + (size_t)ref * kWinK) + (q % (kStage / 2));
-    };
-    uint4 pf[4];
+    // head of this lane's list for the next block, fetched one block ahead
+    auto list_of = [&](int ref) { return A.win_list + (size_t)min(ref, max(A.n_ref - 1, 0)) * kSortK; };
+    uint4 pf[kHead / 2];
     int pf_n = -1;
     if (A.n_ref > 0) {
+        const uint4* lp = (const uint4*)list_of(lane);
 #pragma unroll
-        for (int j = 0; j < 4; j++) pf[j] = *stage_ptr(0, j);
+        for (int j = 0; j < kHead / 2; j++) pf[j] = lp[j];
         if (lane < A.n_ref) pf_n = A.win_n[lane];
     }
     for (int base = 0; base < A.n_ref; base += 64) {
         const int n = pf_n;
+        int ex[kHead], ed[kHead];
 #pragma unroll
-        for (int j = 0; j < 4; j++) ((uint4*)s_stage)[lane + 64 * j] = pf[j];
+        for (int j = 0; j < kHead / 2; j++) {
+            ex[2 * j] = (int)pf[j].x;
+            ed[2 * j] = (int)pf[j].y;
+            ex[2 * j + 1] = (int)pf[j].z;
+            ed[2 * j + 1] = (int)pf[j].w;
+        }
+#pragma unroll
+        for (int k = 0; k < kHead; k++)
+            if (k >= n) ex[k] = 0;  // entries past the end are never chosen; keep their flag lookups in range
         if (base + 64 < A.n_ref) {
+            const uint4* lp = (const uint4*)list_of(base + 64 + lane);
 #pragma unroll
-            for (int j = 0; j < 4; j++) pf[j] = *stage_ptr(base + 64, j);
+            for (int j = 0; j < kHead / 2; j++) pf[j] = lp[j];
             pf_n = base + 64 + lane < A.n_ref ? A.win_n[base + 64 + lane] : -1;
         }
-        wave_lds_fence();
         const int ref_idx = base + lane;
-        const int2* my_list = A.win_list + (size_t)min(ref_idx, max(A.n_ref - 1, 0)) * kWinK;
-        int cursor = 0;
+        const int2* my_list = list_of(ref_idx);
+        int cursor = kHead;  // position in the part of the list that is read from memory
         bool done = !(n > 0);
-        unsigned long long ovm = __ballot(n > kWinK);
+        unsigned long long ovm = __ballot(n > kSortK);
         while (true) {
             const int limit = ovm ? __ffsll((long long)ovm) - 1 : 64;
             while (true) {
                 bool prop = false;
                 int f = 0, d = 0;
                 if (lane < limit && !done) {
-                    int2 e = make_int2(0, 0);
-                    while (cursor < n) {
-                        e = cursor < kStage ? s_stage[lane * kStage + cursor] : my_list[cursor];
-                        if (!(s_matched[e.x] > 0)) break;
-                        cursor++;
+                    int fl[kHead];
+#pragma unroll
+                    for (int k = 0; k < kHead; k++) fl[k] = s_matched[ex[k]];
+                    bool found = false;
+#pragma unroll
+                    for (int k = kHead - 1; k >= 0; k--)
+                        if (k < n && !(fl[k] > 0)) { found = true; f = ex[k]; d = ed[k]; }
+                    if (!found && n > kHead) {
+                        while (cursor < n) {
+                            const int2 e = my_list[cursor];
+                            if (!(s_matched[e.x] > 0)) { found = true; f = e.x; d = e.y; break; }
+                            cursor++;
+                        }
                     }
-                    if (cursor >= n || e.y > 100) done = true;
-                    else { prop = true; f = e.x; d = e.y; }
+                    if (!found || d > 100) done = true;
+                    else prop = true;
                 }
                 if (__ballot(prop) == 0ull) break;
                 if (prop) atomicMin(&s_claim[f], lane);
@@ -990,14 +1006,30 @@ __global__ __launch_bounds__(64) void k_resolve_sorted(ProjArgs A) {
     __syncthreads();
     if (A.check_orientation) {
         const float factor = 1.0f / 30;
-        for (int i = lane; i < n_push; i += 64) {
-            float rot = A.ref_kps[s_push[2 * i]].angle - A.kps[s_push[2 * i + 1]].angle;
-            if (rot < 0.0f) rot += 360.0f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == 30) bin = 0;
-            if (bin < 0 || bin >= 30) bin = -1;
-            else atomicAdd(&s_hist[bin], 1);
-            s_push[2 * i] = bin;
+        // four pushes per lane and step: the eight angle loads of a step are in flight together
+        for (int i0 = 0; i0 < n_push; i0 += 256) {
+            float ra[4], fa[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + 64 * u + lane;
+                ra[u] = fa[u] = 0.f;
+                if (i < n_push) {
+                    ra[u] = A.ref_kps[s_push[2 * i]].angle;
+                    fa[u] = A.kps[s_push[2 * i + 1]].angle;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + 64 * u + lane;
+                if (i >= n_push) continue;
+                float rot = ra[u] - fa[u];
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == 30) bin = 0;
+                if (bin < 0 || bin >= 30) bin = -1;
+                else atomicAdd(&s_hist[bin], 1);
+                s_push[2 * i] = bin;
+            }
         }
         __syncthreads();
         int ind1 = -1, ind2 = -1, ind3 = -1;
@@ -1273,6 +1305,7 @@ static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g,
     ORBX_HIP(hipMemsetAsync(h->d_win_over.p, 0, sizeof(int32_t), s));
     A.win_n = h->d_win_n.p;
     A.win_list = h->d_win_list.p;
+    A.win_stride = kWinK;
     A.win_overflow = h->d_win_over.p;
     const size_t shmem = sizeof(int32_t) * (size_t)n;
     if (mode == 0) {
@@ -1361,14 +1394,16 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     A.status = h->d_ints.p;
     A.n_matches = d_n_matches;
     ORBX_TRY(h->d_win_n.ensure((size_t)kp_capacity * n_pairs));
-    ORBX_TRY(h->d_win_list.ensure((size_t)kp_capacity * n_pairs * kWinK));
+    ORBX_TRY(h->d_win_list.ensure((size_t)kp_capacity * n_pairs * kSortK));
     ORBX_TRY(h->d_win_over.ensure(n_pairs));
     ORBX_HIP(hipMemsetAsync(h->d_win_over.p, 0, sizeof(int32_t) * n_pairs, s));
     A.win_n = h->d_win_n.p;
     A.win_list = h->d_win_list.p;
     A.win_overflow = h->d_win_over.p;
     A.need_slow = h->d_win_over.p;
+    A.win_stride = kSortK;
     if (kp_capacity > 6144) {
+        A.win_stride = kWinK;
         // the speculative resolve keeps five words per feature in LDS; beyond that use the sequential one
         hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A);
         const size_t lds = sizeof(int32_t) * 4 * (size_t)kp_capacity;
