@@ -252,6 +252,9 @@ int orbx_ransac_last_timings(const orbx_ransac* h, float* ms, int cap);
    (std::nth_element + std::partition, the order-defining step of cv::ORB::detect) on the host.  perm_out receives
    the original indices of the kept responses in their final order. */
 orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, int32_t* perm_out, int* new_n);
+/* The same on the device, by the wave-parallel form the batch extractor uses (n <= 8192). */
+orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int n, int n_points, int32_t* perm_out,
+                                             int* new_n);
 
 /* Sets the HIP stream (hipStream_t as void*) a handle launches on; NULL restores the handle's own stream. */
 orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream);

@@ -31,6 +31,10 @@ struct orbx_extractor {
     int device = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // the blur needs only the pyramid: it runs on a side stream next to FAST / emission / selection
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_pyramid = nullptr, ev_blur = nullptr;
+    bool blur_forked = false;
 
     // geometry of the current image size
     int cur_w = -1, cur_h = -1, cur_levels = -1;
@@ -274,7 +278,7 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
 
 // Pyramid + FAST + NMS + ordered emission + Harris/angle for `frames` device-resident images.
 orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int frames, size_t frame_stride, int w,
-                             int hgt, int stride, int ch) {
+                             int hgt, int stride, int ch, bool fork_blur = false) {
     const Geom& g = h->geom;
     hipStream_t s = h->stream;
     size_t A = h->atlas_bytes;
@@ -283,7 +287,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     const int border = g.border;
     T.begin(ST_GRAY, s);
     {
-        dim3 grid(div_up(w + 2 * border, 256), hgt + 2 * border, frames);
+        dim3 grid(div_up(div_up(w + 2 * border + 3, 4), 64), div_up(hgt + 2 * border, 4), frames);
         hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch,
                            h->d_atlas.p, A, g.atlas_w, g.L[0].x, g.L[0].y, border);
     }
@@ -300,6 +304,17 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     hipLaunchKernelGGL(k_fast_nms<false>, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p,
                        h->d_mask.p, A, g, h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255), 0);
     T.end(ST_FAST, s);
+    // forked here, not right after the pyramid: FAST fills the chip by itself, emission and selection do not
+    if (fork_blur) {
+        ORBX_HIP(hipEventRecord(h->ev_pyramid, s));
+        ORBX_HIP(hipStreamWaitEvent(h->side_stream, h->ev_pyramid, 0));
+        T.begin(ST_BLUR, h->side_stream);
+        hipLaunchKernelGGL(k_blur, dim3(div_up((int)h->strips.size(), 4), frames), dim3(256), 0, h->side_stream,
+                           h->d_atlas.p, h->d_blur.p, A, g, h->d_strips.p, (int)h->strips.size(), h->blur_taps);
+        T.end(ST_BLUR, h->side_stream);
+        ORBX_HIP(hipEventRecord(h->ev_blur, h->side_stream));
+        h->blur_forked = true;
+    }
     T.begin(ST_EMIT, s);
     hipLaunchKernelGGL(k_emit, dim3(frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, h->d_cand.p,
                        h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
@@ -321,7 +336,7 @@ orbx_status run_pyramid(orbx_extractor* h, const uint8_t* d_images, int frames, 
     size_t A = h->atlas_bytes;
     const int border = g.border;
     h->timer.begin(ST_GRAY, s);
-    dim3 grid(div_up(w + 2 * border, 256), hgt + 2 * border, frames);
+    dim3 grid(div_up(div_up(w + 2 * border + 3, 4), 64), div_up(hgt + 2 * border, 4), frames);
     hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch, h->d_atlas.p,
                        A, g.atlas_w, g.L[0].x, g.L[0].y, border);
     h->timer.end(ST_GRAY, s);
@@ -342,10 +357,15 @@ orbx_status run_describe_stage(orbx_extractor* h, int frames) {
     const Geom& g = h->geom;
     hipStream_t s = h->stream;
     size_t A = h->atlas_bytes;
-    h->timer.begin(ST_BLUR, s);
-    hipLaunchKernelGGL(k_blur, dim3(div_up((int)h->strips.size(), 4), frames), dim3(256), 0, s, h->d_atlas.p,
-                       h->d_blur.p, A, g, h->d_strips.p, (int)h->strips.size(), h->blur_taps);
-    h->timer.end(ST_BLUR, s);
+    if (h->blur_forked) {
+        ORBX_HIP(hipStreamWaitEvent(s, h->ev_blur, 0));
+        h->blur_forked = false;
+    } else {
+        h->timer.begin(ST_BLUR, s);
+        hipLaunchKernelGGL(k_blur, dim3(div_up((int)h->strips.size(), 4), frames), dim3(256), 0, s, h->d_atlas.p,
+                           h->d_blur.p, A, g, h->d_strips.p, (int)h->strips.size(), h->blur_taps);
+        h->timer.end(ST_BLUR, s);
+    }
     h->timer.begin(ST_BRIEF, s);
     hipLaunchKernelGGL(k_brief, dim3(div_up(h->kp_cap, 8), frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A, g,
                        h->d_kp.p, h->d_kp_counts.p, h->kp_cap, h->d_desc.p, h->d_pattern.p);
@@ -440,6 +460,12 @@ orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_w
         return ORBX_DEVICE;
     }
     h->stream = h->own_stream;
+    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_pyramid, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess) {
+        orbx_extractor_destroy(h);
+        return ORBX_DEVICE;
+    }
     orbx_status st = h->timer.init();
     if (st != ORBX_OK) { orbx_extractor_destroy(h); return st; }
 
@@ -508,6 +534,9 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_cell_start.release(); h->d_cell_items.release(); h->h_cell_start.release(); h->h_cell_items.release();
     h->d_status.release();
     h->timer.destroy();
+    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+    if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
+    if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -562,6 +591,28 @@ orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, ui
     }
     ORBX_HIP(hipStreamSynchronize(h->stream));
     ORBX_HIP(hipMemcpy(out, src + (size_t)frame * h->atlas_bytes, h->atlas_bytes, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int n, int n_points, int32_t* perm_out,
+                                             int* n_out) {
+    if (!keys || !perm_out || !n_out || n < 0 || n > kSelectMaxCands) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(device));
+    DevBuf<float> d_keys;
+    DevBuf<int> d_out;
+    ORBX_TRY(d_keys.ensure(std::max(n, 1)));
+    ORBX_TRY(d_out.ensure((size_t)n + 1));
+    ORBX_HIP(hipMemcpy(d_keys.p, keys, sizeof(float) * n, hipMemcpyHostToDevice));
+    const size_t shmem = (size_t)std::max(n, 1) * (sizeof(stdsel::Elem) + 2 * sizeof(uint16_t)) + 16;
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_selftest_retain_best, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)shmem));
+    hipLaunchKernelGGL(k_selftest_retain_best, dim3(1), dim3(64), shmem, 0, d_keys.p, n, n_points, d_out.p + 1, d_out.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipDeviceSynchronize());
+    ORBX_HIP(hipMemcpy(n_out, d_out.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (*n_out > 0) ORBX_HIP(hipMemcpy(perm_out, d_out.p + 1, sizeof(int) * (size_t)*n_out, hipMemcpyDeviceToHost));
+    d_keys.release();
+    d_out.release();
     return ORBX_OK;
 }
 
@@ -650,7 +701,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
     ORBX_TRY(ensure_buffers(h, n_frames));
     h->last_frames = n_frames;
-    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels));
+    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, true));
 
     // Device-resident path: selection, undistortion, bucket grid and border filter run in one kernel per frame
     // (k_select_frame), so nothing crosses PCIe between detect and compute.  It covers frames whose candidates fit
@@ -676,7 +727,9 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         fm.height = height;
         fm.edge = h->prm.edge_threshold;
         fm.patch_size = h->prm.patch_size;
-        const size_t shmem = sizeof(stdsel::Elem) * kSelectMaxCands + (size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int));
+        const size_t shmem = sizeof(stdsel::Elem) * kSelectMaxCands +
+                             std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)),
+                                      sizeof(uint16_t) * 2 * (size_t)kSelectMaxCands);
         if (!h->select_attr_set || shmem > h->select_attr_bytes) {
             ORBX_HIP(hipFuncSetAttribute((const void*)k_select_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             h->select_attr_set = true;

@@ -18,42 +18,53 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-// K1: BGR/gray -> level 0 of the atlas including its reflect-101 border.
-// cv::cvtColor(BGR2GRAY) 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14.
-__global__ void k_gray_level0(const uint8_t* __restrict__ img, size_t frame_stride, int w, int h, int stride, int ch,
-                              uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw, int rx, int ry, int border) {
-    int tx = blockIdx.x * blockDim.x + threadIdx.x;
-    int ty = blockIdx.y;
-    int b = blockIdx.z;
-    if (tx >= w + 2 * border) return;
-    int sx = reflect101(tx - border, w), sy = reflect101(ty - border, h);
-    const uint8_t* s = img + (size_t)b * frame_stride + (size_t)sy * stride + (size_t)sx * ch;
-    int g;
-    if (ch == 1) g = s[0];
-    else g = (s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14;
-    atlas[(size_t)b * atlas_bytes + (size_t)(ry - border + ty) * aw + (rx - border + tx)] = (uint8_t)g;
+// Four bytes from any address; the compiler picks the widest load the target allows for byte alignment.
+__device__ __forceinline__ unsigned load_u32_any(const uint8_t* p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
 }
 
-// K2: level l from level l-1 by cv::resize(INTER_LINEAR_EXACT) (Q8.8 horizontal, Q16.16 vertical, round half up),
-// written together with its reflect-101 border.
-__global__ void k_resize_level(uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw, LevelInfo src, LevelInfo dst,
-                               const Coef* __restrict__ coef, int border) {
-    int tx = blockIdx.x * blockDim.x + threadIdx.x;
-    int ty = blockIdx.y;
-    int b = blockIdx.z;
-    if (tx >= dst.w + 2 * border) return;
-    int x = reflect101(tx - border, dst.w), y = reflect101(ty - border, dst.h);
-    Coef cx = coef[dst.coef_x + x], cy = coef[dst.coef_y + y];
-    uint8_t* base = atlas + (size_t)b * atlas_bytes;
-    int o = cx.ofs, o1 = min(o + 1, src.w - 1);
-    int r = cy.ofs, r1 = min(r + 1, src.h - 1);
-    const uint8_t* p0 = base + (size_t)(src.y + r) * aw + src.x;
-    const uint8_t* p1 = base + (size_t)(src.y + r1) * aw + src.x;
-    uint32_t wx1 = (uint32_t)cx.w1, wx0 = 256u - wx1, wy1 = (uint32_t)cy.w1, wy0 = 256u - wy1;
-    uint32_t h0 = wx0 * p0[o] + wx1 * p0[o1];
-    uint32_t h1 = wx0 * p1[o] + wx1 * p1[o1];
-    uint32_t v = wy0 * h0 + wy1 * h1;
-    base[(size_t)(dst.y - border + ty) * aw + (dst.x - border + tx)] = (uint8_t)((v + (1u << 15)) >> 16);
+__device__ __forceinline__ unsigned gray_of(unsigned b, unsigned g, unsigned r) {
+    return (b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14;
+}
+
+// K1: BGR/gray -> level 0 of the atlas including its reflect-101 border, four atlas pixels per lane.
+// cv::cvtColor(BGR2GRAY) 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+__global__ __launch_bounds__(256) void k_gray_level0(const uint8_t* __restrict__ img, size_t frame_stride, int w, int h,
+                                                     int stride, int ch, uint8_t* __restrict__ atlas,
+                                                     size_t atlas_bytes, int aw, int rx, int ry, int border) {
+    const int q = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ty = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const int ax_begin = (rx - border) & ~3;
+    const int ax = ax_begin + 4 * q;             // first of this lane's four atlas columns
+    const int x_first = rx - border, x_last = rx + w + border;
+    if (ax >= x_last || ty >= h + 2 * border) return;
+    const int sy = reflect101(ty - border, h);
+    const uint8_t* row = img + (size_t)b * frame_stride + (size_t)sy * stride;
+    uint8_t* d = atlas + (size_t)b * atlas_bytes + (size_t)(ry - border + ty) * aw + ax;
+    const int sx = ax - rx;
+    if (sx >= 0 && sx + 3 < w) {  // interior: 4 (gray) or 12 (BGR) contiguous source bytes
+        unsigned out;
+        if (ch == 1) out = load_u32_any(row + sx);
+        else {
+            const uint8_t* s = row + (size_t)sx * 3;
+            const unsigned w0 = load_u32_any(s), w1 = load_u32_any(s + 4), w2 = load_u32_any(s + 8);
+            out = gray_of(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u) |
+                  gray_of(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u) << 8 |
+                  gray_of((w1 >> 16) & 255u, w1 >> 24, w2 & 255u) << 16 |
+                  gray_of((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24) << 24;
+        }
+        *(unsigned*)d = out;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (ax + j < x_first || ax + j >= x_last) continue;
+        const uint8_t* s = row + (size_t)reflect101(sx + j, w) * ch;
+        d[j] = (uint8_t)(ch == 1 ? s[0] : gray_of(s[0], s[1], s[2]));
+    }
 }
 
 // K2 (dword-wise): level l from level l-1 by cv::resize(INTER_LINEAR_EXACT), border included.  A lane produces four
@@ -383,13 +394,6 @@ __device__ __forceinline__ int wave_sum_uniform(int v) {
            __builtin_amdgcn_readlane(v, 48);
 }
 
-// Four bytes from any address; the compiler picks the widest load the target allows for byte alignment.
-__device__ __forceinline__ unsigned load_u32_any(const uint8_t* p) {
-    unsigned v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
-
 // K5/K6: Harris response (cv::ORB HarrisResponses, 7x7 block, k = 0.04) and intensity-centroid angle
 // (cv::ORB ICAngles, radius 15) of one candidate per wavefront.  Candidates whose FAST score is below the level's
 // retainBest(2*quota) value are skipped: cv::ORB has dropped them before it computes either quantity.
@@ -510,8 +514,8 @@ __device__ __forceinline__ int compact_ordered(orbx_keypoint* s_kp, int n, int l
 
 // Device half of cv::ORB::detect after the kernels above, plus the host steps MonoFrame::extractFeatures performs
 // between detect and compute - one workgroup per frame, one wavefront per pyramid level:
-//   retainBest(2*quota) on the FAST score, retainBest(quota) on the Harris response (lane 0 of the level's wave
-//   replays libstdc++'s nth_element + partition, stdsel.h), keypoint assembly (size, angle, level-0 coordinates),
+//   retainBest(2*quota) on the FAST score, retainBest(quota) on the Harris response (the level's wave replays
+//   libstdc++'s nth_element + partition, stdsel.h), keypoint assembly (size, angle, level-0 coordinates),
 //   Camera::undistortPoints, Frame::assignFeaturesToGrid (ordered filter + CSR cells), and the border filter of
 //   cv::ORB::compute.  status[frame]: 0 ok, 1 more keypoints than kp_cap, 2 more candidates than the LDS holds.
 __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ cand, int cand_cap,
@@ -526,6 +530,9 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     orbx_keypoint* s_kp = (orbx_keypoint*)(s_raw + sizeof(stdsel::Elem) * kSelectMaxCands);  // [kp_cap]
     int* s_cell = (int*)(s_kp + kp_cap);                                         // [kp_cap]
     int* s_cells = (int*)s_raw;                                                  // [ncell + 1], aliases s_el later
+    // stopper lists of the wave-parallel partitions; they alias s_kp / s_cell, which are idle during the selection
+    uint16_t* s_lp = (uint16_t*)s_kp;                                            // [kSelectMaxCands]
+    uint16_t* s_rp = s_lp + kSelectMaxCands;                                     // [kSelectMaxCands]
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, lvl = tid >> 6;
     const Cand* cd = cand + (size_t)b * cand_cap;
@@ -541,17 +548,15 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
         for (int i = lane; i < n; i += 64) s_el[off + i] = stdsel::Elem{(float)cd[off + i].score, off + i};
     }
     __syncthreads();
-    if (lvl < g.nlevels && lane == 0) n = stdsel::retain_best(s_el + off, n, 2 * g.L[lvl].quota);
-    n = __shfl(n, 0);
+    if (lvl < g.nlevels) n = stdsel::wave_retain_best(s_el + off, n, 2 * g.L[lvl].quota, s_lp + off, s_rp + off, lane);
     __syncthreads();
     if (lvl < g.nlevels)
         for (int i = lane; i < n; i += 64) s_el[off + i].key = cd[s_el[off + i].idx].harris;
     __syncthreads();
-    if (lvl < g.nlevels && lane == 0) {
-        n = stdsel::retain_best(s_el + off, n, g.L[lvl].quota);
-        s_n[lvl] = n;
+    if (lvl < g.nlevels) {
+        n = stdsel::wave_retain_best(s_el + off, n, g.L[lvl].quota, s_lp + off, s_rp + off, lane);
+        if (lane == 0) s_n[lvl] = n;
     }
-    n = __shfl(n, 0);
     __syncthreads();
     if (tid == 0) {
         int acc = 0;
@@ -673,6 +678,22 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     orbx_keypoint* out = kps_out + (size_t)b * kp_cap;
     for (int i = tid; i < count; i += blockDim.x) out[i] = s_kp[i];
     if (tid == 0) { kp_counts[b] = count; status[b] = 0; }
+}
+
+// Test hook: retainBest of an arbitrary key array by the wave-parallel replay (one wavefront).
+__global__ __launch_bounds__(64) void k_selftest_retain_best(const float* __restrict__ keys, int n, int n_points,
+                                                             int* __restrict__ perm_out, int* __restrict__ n_out) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    stdsel::Elem* s_el = (stdsel::Elem*)s_raw;
+    uint16_t* s_lp = (uint16_t*)(s_el + n);
+    uint16_t* s_rp = s_lp + n;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n; i += 64) s_el[i] = stdsel::Elem{keys[i], i};
+    __syncthreads();
+    const int m = stdsel::wave_retain_best(s_el, n, n_points, s_lp, s_rp, lane);
+    __syncthreads();
+    for (int i = lane; i < m; i += 64) perm_out[i] = s_el[i].idx;
+    if (lane == 0) *n_out = m;
 }
 
 // Packs the per-frame candidate lists back to back (offsets = exclusive prefix of totals) for one D2H copy.

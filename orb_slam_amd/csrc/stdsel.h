@@ -188,5 +188,108 @@ ORBX_HD inline int retain_best(Elem* a, int n, int n_points) {
     return n;
 }
 
+#if defined(__HIPCC__)
+// ---- the same algorithms carried out by one wavefront -------------------------------------------------------------
+// The partitions are where the time goes, and their result can be formed without walking the two pointers: the
+// left pointer stops exactly at the original positions whose element does not pass its test ("left stoppers", in
+// ascending order), the right pointer at those that do not pass the other test ("right stoppers", descending); the
+// serial loop swaps the k-th left stopper with the k-th right stopper for as long as the former lies left of the
+// latter.  Ranks come from ballots, the swaps are independent, and the returned cut follows from the first pair
+// that is not swapped.  Pivot choice, the final insertion sort and the heap-select fallback stay serial on lane 0
+// (they touch a handful of elements, or never run on real data).  a, lp and rp are LDS arrays; every lane of the
+// wavefront must call with the same arguments.
+
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// MODE 0: std::__unguarded_partition(lo, hi, pivot) for KeypointResponseGreater, pivot key p; returns the cut.
+// MODE 1: std::partition(lo, hi, key >= p), bidirectional form; returns the partition point.
+template <int MODE>
+__device__ inline int wave_partition(Elem* a, int lo, int hi, float p, uint16_t* lp, uint16_t* rp, int lane) {
+    int nL = 0, nR = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool in = i < hi;
+        const float k = in ? a[i].key : 0.f;
+        const bool is_l = in && (MODE == 0 ? !(k > p) : !(k >= p));
+        const bool is_r = in && (MODE == 0 ? !(p > k) : (k >= p));
+        const unsigned long long bl = __ballot(is_l), br = __ballot(is_r);
+        if (is_l) lp[nL + __popcll(bl & below)] = (uint16_t)(i - lo);
+        if (is_r) rp[nR + __popcll(br & below)] = (uint16_t)(i - lo);
+        nL += __popcll(bl);
+        nR += __popcll(br);
+    }
+    wave_sync();
+    // k-th right stopper counted from the right end: rp[nR - 1 - k]
+    const int nmin = nL < nR ? nL : nR;
+    int K = 0;
+    for (int base = 0; base < nmin; base += 64) {
+        const int k = base + lane;
+        const bool sw = k < nmin && lp[k] < rp[nR - 1 - k];
+        const unsigned long long b = __ballot(sw);
+        K += __popcll(b);
+        if (b != ~0ull) break;  // the test is monotone in k
+    }
+    for (int base = 0; base < K; base += 64) {
+        const int k = base + lane;
+        if (k < K) {
+            const int i = lo + lp[k], j = lo + rp[nR - 1 - k];
+            const Elem t = a[i];
+            a[i] = a[j];
+            a[j] = t;
+        }
+    }
+    int cut;
+    if (MODE == 0) {
+        const int l_next = K < nL ? (int)lp[K] : 0x7fffffff;
+        const int r_prev = K > 0 ? (int)rp[nR - K] : 0x7fffffff;
+        cut = lo + (l_next < r_prev ? l_next : r_prev);
+    } else {
+        cut = lo + nR;
+    }
+    wave_sync();
+    return cut;
+}
+
+__device__ inline void wave_nth_element(Elem* a, int first, int nth, int last, uint16_t* lp, uint16_t* rp, int lane) {
+    if (first == last || nth == last) return;
+    int depth_limit = lg(last - first) * 2;
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            if (lane == 0) {
+                heap_select(a + first, a + nth + 1, a + last);
+                swap_elem(a + first, a + nth);
+            }
+            wave_sync();
+            return;
+        }
+        --depth_limit;
+        if (lane == 0) move_median_to_first(a + first, a + first + 1, a + first + (last - first) / 2, a + last - 1);
+        wave_sync();
+        const float pivot = a[first].key;
+        const int cut = wave_partition<0>(a, first + 1, last, pivot, lp, rp, lane);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0) insertion_sort(a + first, a + last);
+    wave_sync();
+}
+
+// cv::KeyPointsFilter::retainBest by one wavefront; lp / rp hold n 16-bit entries each.  Returns the new length.
+__device__ inline int wave_retain_best(Elem* a, int n, int n_points, uint16_t* lp, uint16_t* rp, int lane) {
+    if (n_points >= 0 && n > n_points) {
+        if (n_points == 0) return 0;
+        wave_nth_element(a, 0, n_points - 1, n, lp, rp, lane);
+        const float ambiguous = a[n_points - 1].key;
+        return wave_partition<1>(a, n_points, n, ambiguous, lp, rp, lane);
+    }
+    return n;
+}
+#endif  // __HIPCC__
+
 }  // namespace stdsel
 }  // namespace orbx

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -386,6 +386,15 @@ def selftest_retain_best(keys, n_points):
     n = C.c_int()
     _check(lib().orbx_selftest_retain_best(_p(keys), len(keys), n_points, _p(perm), C.byref(n)),
            "orbx_selftest_retain_best")
+    return perm[:n.value].copy()
+
+
+def selftest_retain_best_device(keys, n_points, device=0):
+    keys = np.ascontiguousarray(keys, np.float32)
+    perm = np.zeros(max(len(keys), 1), np.int32)
+    n = C.c_int()
+    _check(lib().orbx_selftest_retain_best_device(device, _p(keys), len(keys), n_points, _p(perm), C.byref(n)),
+           "orbx_selftest_retain_best_device")
     return perm[:n.value].copy()
 
 

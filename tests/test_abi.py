@@ -79,9 +79,7 @@ def test_ransac_sets_match_oracle(oracle):
     assert all(len(set(r.tolist())) == 8 for r in s)
 
 
-def test_retain_best_replay_matches_libstdcxx(oracle):
-    """The library's replay of std::nth_element + std::partition leaves the kept keypoints in exactly the order the
-    real libstdc++ calls do, including tie-heavy inputs (FAST scores are small integers) and the heap-select path."""
+def retain_best_cases():
     rng = np.random.default_rng(11)
     cases = []
     for n in (0, 1, 2, 3, 4, 5, 17, 100, 1000, 4583):
@@ -110,7 +108,13 @@ def test_retain_best_replay_matches_libstdcxx(oracle):
     k[half:] = 2 * (np.arange(half) + 1)
     cases.append((-k, 1000))
     cases.append((k, 37))
-    for keys, npts in cases:
+    return cases
+
+
+def test_retain_best_replay_matches_libstdcxx(oracle):
+    """The library's replay of std::nth_element + std::partition leaves the kept keypoints in exactly the order the
+    real libstdc++ calls do, including tie-heavy inputs (FAST scores are small integers) and the heap-select path."""
+    for keys, npts in retain_best_cases():
         a = orbx.selftest_retain_best(keys, npts)
         b = oracle.retain_best(keys, npts)
         assert np.array_equal(a, b), (len(keys), npts)

@@ -411,3 +411,18 @@ def test_frame_model_batch_and_batched_projection(oracle, test_images):
             assert hn.min() > 100
     ex.close()
     mt.close()
+
+
+def test_wave_parallel_retain_best_matches_libstdcxx(oracle):
+    """The wave-parallel nth_element + partition of the device selection leaves the kept responses in the order the
+    real libstdc++ calls do: ties, sorted / reversed / constant inputs, and the heap-select fallback."""
+    from tests.test_abi import retain_best_cases
+    rng = np.random.default_rng(12)
+    cases = retain_best_cases()
+    for n in (63, 64, 65, 129, 2500, 8192):
+        cases.append((rng.integers(20, 40, n).astype(np.float32), n // 4))
+        cases.append((rng.normal(size=n).astype(np.float32), n // 2))
+    for keys, npts in cases:
+        a = orbx.selftest_retain_best_device(keys, npts)
+        b = oracle.retain_best(keys, npts)
+        assert np.array_equal(a, b), (len(keys), npts)
