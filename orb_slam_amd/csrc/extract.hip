@@ -316,7 +316,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
         h->blur_forked = true;
     }
     T.begin(ST_EMIT, s);
-    hipLaunchKernelGGL(k_emit, dim3(frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, h->d_cand.p,
+    hipLaunchKernelGGL(k_emit, dim3(frames), dim3(1024), 0, s, h->d_mask.p, h->d_score.p, A, g, h->d_cand.p,
                        h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);

@@ -264,43 +264,60 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     }
 }
 
-// K4b: ordered emission. One workgroup per frame walks the mask words in level-major raster order and appends the
-// set bits at their exact rank, so the candidate list has the order cv::FAST emits.  Also builds the per-level
-// histogram of FAST scores and from it the score of the (2*quota)-th best corner: the value
+// Inclusive prefix sum over the 64 lanes (DPP row shifts, then the two cross-row broadcasts).
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
+    return v;
+}
+
+// K4b: ordered emission.  One workgroup per frame; each of its 16 wavefronts owns a contiguous run of mask words
+// (level-major raster order), counts its set bits, and after one exchange of the 16 totals appends its corners at
+// their exact rank, so the candidate list has the order cv::FAST emits.  Also builds the per-level histogram of
+// FAST scores and from it the score of the (2*quota)-th best corner: the value
 // KeyPointsFilter::retainBest(2*quota) keeps everything at or above.
-__global__ __launch_bounds__(256) void k_emit(const unsigned long long* __restrict__ mask,
-                                              const uint8_t* __restrict__ score, size_t atlas_bytes, Geom g,
-                                              Cand* __restrict__ cand, int cap, int* __restrict__ level_counts,
-                                              int* __restrict__ thresholds, int* __restrict__ totals) {
+__global__ __launch_bounds__(1024) void k_emit(const unsigned long long* __restrict__ mask,
+                                               const uint8_t* __restrict__ score, size_t atlas_bytes, Geom g,
+                                               Cand* __restrict__ cand, int cap, int* __restrict__ level_counts,
+                                               int* __restrict__ thresholds, int* __restrict__ totals) {
     __shared__ int hist[kMaxLevels][256];
     __shared__ int lcount[kMaxLevels];
-    __shared__ int wave_sum[4];
-    __shared__ int running;
+    __shared__ int wave_tot[16];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < kMaxLevels * 256; i += 256) (&hist[0][0])[i] = 0;
+    for (int i = tid; i < kMaxLevels * 256; i += 1024) (&hist[0][0])[i] = 0;
     if (tid < kMaxLevels) lcount[tid] = 0;
-    if (tid == 0) running = 0;
-    __syncthreads();
     const unsigned long long* mk = mask + (size_t)b * g.total_words;
     const uint8_t* sc = score + (size_t)b * atlas_bytes;
     Cand* out = cand + (size_t)b * cap;
     const int lane = tid & 63, wv = tid >> 6;
-    for (int base = 0; base < g.total_words; base += 256) {
-        const int word = base + tid;
-        unsigned long long m = word < g.total_words ? mk[word] : 0ull;
+    const int per = ((g.total_words + 15) / 16 + 63) / 64 * 64;
+    const int w0 = min(wv * per, g.total_words), w1 = min(w0 + per, g.total_words);
+    int mine = 0;
+    for (int base = w0; base < w1; base += 64) {
+        const int word = base + lane;
+        mine += word < w1 ? __popcll(mk[word]) : 0;
+    }
+    mine = wave_scan_incl(mine);
+    if (lane == 63) wave_tot[wv] = mine;
+    __syncthreads();
+    int running = 0, all = 0;
+    for (int k = 0; k < 16; k++) {
+        const int t = wave_tot[k];
+        if (k < wv) running += t;
+        all += t;
+    }
+    for (int base = w0; base < w1; base += 64) {
+        const int word = base + lane;
+        unsigned long long m = word < w1 ? mk[word] : 0ull;
         const int c = __popcll(m);
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wave_sum[wv] = incl;
-        __syncthreads();
-        int before = running;
-        for (int k = 0; k < wv; k++) before += wave_sum[k];
-        int pos = before + incl - c;
+        const int incl = wave_scan_incl(c);
+        int pos = running + incl - c;
+        running += __builtin_amdgcn_readlane(incl, 63);
         if (m) {
             int l = 0;
             while (l + 1 < g.nlevels && word >= g.L[l + 1].word_base) l++;
@@ -329,10 +346,8 @@ __global__ __launch_bounds__(256) void k_emit(const unsigned long long* __restri
                 pos++;
             }
         }
-        __syncthreads();
-        if (tid == 0) running += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
-        __syncthreads();
     }
+    __syncthreads();
     if (tid < g.nlevels) {
         const int n = lcount[tid];
         const int want = 2 * g.L[tid].quota;
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256) void k_emit(const unsigned long long* __restri
         level_counts[b * kMaxLevels + tid] = n;
         thresholds[b * kMaxLevels + tid] = t;
     }
-    if (tid == 0) totals[b] = running;
+    if (tid == 0) totals[b] = all;
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
