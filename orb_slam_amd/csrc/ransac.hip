@@ -44,8 +44,10 @@ orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref,
     hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, h->d_pn.p, h->d_rn.p, h->d_T.p);
     T.end(RT_NORMALIZE, s);
     T.begin(RT_SOLVE, s);
-    hipLaunchKernelGGL(k_solve, dim3(div_up(iterations, 64), pairs), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p,
-                       d_sets8, iterations, h->d_Fall.p, h->d_Hall.p, h->d_Hiall.p);
+    hipLaunchKernelGGL(k_solve_f, dim3(div_up(iterations, 64), pairs), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n,
+                       h->d_T.p, d_sets8, iterations, h->d_Fall.p);
+    hipLaunchKernelGGL(k_solve_h, dim3(div_up(iterations, 64), pairs), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n,
+                       h->d_T.p, d_sets8, iterations, h->d_Hall.p, h->d_Hiall.p);
     T.end(RT_SOLVE, s);
     T.begin(RT_SCORE_F, s);
     hipLaunchKernelGGL(k_score_f, dim3(div_up(iterations, 256), pairs), dim3(256), 0, s, d_points, d_ref, n,

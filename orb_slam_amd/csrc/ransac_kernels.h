@@ -51,41 +51,43 @@ __device__ __forceinline__ double hypot_f64(double x, double y) {
 }
 
 // cv::JacobiSVDImpl_<float> (OpenCV 3.4 core/lapack.cpp): one-sided Jacobi on the N rows (length M) of At, with
-// the rotations accumulated in Vt (N x N).  The first N1 rows of At are turned into an orthonormal set: rows with
-// a vanishing singular value, and rows >= N, are synthesised from cv::RNG(0x12345678) and Gram-Schmidt, exactly as
-// OpenCV does (for the 8x9 system that synthesised 9th row IS the null vector the reference takes).
-// W receives the singular values (double, sorted descending).  COMPLETE = false skips the At completion when only
-// Vt is wanted.
-template <int M, int N, int N1, bool COMPLETE>
-__device__ void jacobi_svd(float* At, float* Vt, double* W) {
-    const double minval = 1.17549435082228750797e-38;  // FLT_MIN
-    const float eps = 1.1920928955078125e-7f * 2;      // FLT_EPSILON * 2
+// the rotations accumulated in Vt (N x N) when WANT_V.  Every loop over rows and columns is unrolled and every
+// index is a compile-time constant, so At, Vt and W live in registers (one hypothesis per lane, no scratch memory);
+// the operations and their order are those of the scalar loops.  On return W holds the squared row norms as the
+// sweeps left them (OpenCV recomputes them next: see svd_finish).
+template <int M, int N, bool WANT_V>
+__device__ __forceinline__ void jacobi_sweeps(float (&At)[N * M], float (&Vt)[WANT_V ? N * N : 1], double (&W)[N]) {
+    const float eps = 1.1920928955078125e-7f * 2;  // FLT_EPSILON * 2
     const int max_iter = M > 30 ? M : 30;
-    float c, s;
-    double sd;
+#pragma unroll
     for (int i = 0; i < N; i++) {
-        sd = 0;
+        double sd = 0;
+#pragma unroll
         for (int k = 0; k < M; k++) {
-            float t = At[i * M + k];
+            const float t = At[i * M + k];
             sd += (double)t * t;
         }
         W[i] = sd;
-        for (int k = 0; k < N; k++) Vt[i * N + k] = 0;
-        Vt[i * N + i] = 1;
+        if (WANT_V) {
+#pragma unroll
+            for (int k = 0; k < N; k++) Vt[i * N + k] = k == i ? 1.f : 0.f;
+        }
     }
     for (int iter = 0; iter < max_iter; iter++) {
         bool changed = false;
-        for (int i = 0; i < N - 1; i++)
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) {
+#pragma unroll
             for (int j = i + 1; j < N; j++) {
-                float* Ai = At + i * M;
-                float* Aj = At + j * M;
                 double a = W[i], p = 0, b = W[j];
-                for (int k = 0; k < M; k++) p += (double)Ai[k] * Aj[k];
+#pragma unroll
+                for (int k = 0; k < M; k++) p += (double)At[i * M + k] * At[j * M + k];
                 if (fabs(p) <= eps * sqrt((double)a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot_f64((double)p, beta);
+                const double beta = a - b, gamma = hypot_f64((double)p, beta);
+                float c, s;
                 if (beta < 0) {
-                    double delta = (gamma - beta) * 0.5;
+                    const double delta = (gamma - beta) * 0.5;
                     s = (float)sqrt(delta / gamma);
                     c = (float)(p / (gamma * s * 2));
                 } else {
@@ -93,79 +95,120 @@ __device__ void jacobi_svd(float* At, float* Vt, double* W) {
                     s = (float)(p / (gamma * c * 2));
                 }
                 a = b = 0;
+#pragma unroll
                 for (int k = 0; k < M; k++) {
-                    float t0 = c * Ai[k] + s * Aj[k];
-                    float t1 = -s * Ai[k] + c * Aj[k];
-                    Ai[k] = t0;
-                    Aj[k] = t1;
+                    const float t0 = c * At[i * M + k] + s * At[j * M + k];
+                    const float t1 = -s * At[i * M + k] + c * At[j * M + k];
+                    At[i * M + k] = t0;
+                    At[j * M + k] = t1;
                     a += (double)t0 * t0;
                     b += (double)t1 * t1;
                 }
                 W[i] = a;
                 W[j] = b;
                 changed = true;
-                float* Vi = Vt + i * N;
-                float* Vj = Vt + j * N;
-                for (int k = 0; k < N; k++) {
-                    float t0 = c * Vi[k] + s * Vj[k];
-                    float t1 = -s * Vi[k] + c * Vj[k];
-                    Vi[k] = t0;
-                    Vj[k] = t1;
+                if (WANT_V) {
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        const float t0 = c * Vt[i * N + k] + s * Vt[j * N + k];
+                        const float t1 = -s * Vt[i * N + k] + c * Vt[j * N + k];
+                        Vt[i * N + k] = t0;
+                        Vt[j * N + k] = t1;
+                    }
                 }
             }
+        }
         if (!changed) break;
     }
+}
+
+// The rest of JacobiSVDImpl_: singular values from the row norms, selection sort into descending order (first of
+// equal maxima wins, as `W[j] < W[k]` decides), rows of At (SORT_A) and Vt (WANT_V) following.  perm[i] receives the
+// original index of the row that ends at position i.
+template <int M, int N, bool WANT_V, bool SORT_A>
+__device__ __forceinline__ void svd_finish(float (&At)[N * M], float (&Vt)[WANT_V ? N * N : 1], double (&W)[N],
+                                           int (&perm)[N]) {
+#pragma unroll
     for (int i = 0; i < N; i++) {
-        sd = 0;
+        double sd = 0;
+#pragma unroll
         for (int k = 0; k < M; k++) {
-            float t = At[i * M + k];
+            const float t = At[i * M + k];
             sd += (double)t * t;
         }
         W[i] = sqrt(sd);
+        perm[i] = i;
     }
+#pragma unroll
     for (int i = 0; i < N - 1; i++) {
         int j = i;
+        double wj = W[i];
+#pragma unroll
         for (int k = i + 1; k < N; k++)
-            if (W[j] < W[k]) j = k;
-        if (i != j) {
-            double tw = W[i]; W[i] = W[j]; W[j] = tw;
-            for (int k = 0; k < M; k++) { float t = At[i * M + k]; At[i * M + k] = At[j * M + k]; At[j * M + k] = t; }
-            for (int k = 0; k < N; k++) { float t = Vt[i * N + k]; Vt[i * N + k] = Vt[j * N + k]; Vt[j * N + k] = t; }
+            if (wj < W[k]) { j = k; wj = W[k]; }
+#pragma unroll
+        for (int k = i + 1; k < N; k++) {
+            if (j != k) continue;
+            const double tw = W[i]; W[i] = W[k]; W[k] = tw;
+            const int tp = perm[i]; perm[i] = perm[k]; perm[k] = tp;
+            if (SORT_A) {
+#pragma unroll
+                for (int q = 0; q < M; q++) { const float t = At[i * M + q]; At[i * M + q] = At[k * M + q]; At[k * M + q] = t; }
+            }
+            if (WANT_V && SORT_A) {
+#pragma unroll
+                for (int q = 0; q < N; q++) { const float t = Vt[i * N + q]; Vt[i * N + q] = Vt[k * N + q]; Vt[k * N + q] = t; }
+            }
         }
     }
-    if (!COMPLETE) return;
+}
+
+// Completion of the first N1 rows of At to an orthonormal set, as OpenCV does it: rows with a vanishing singular
+// value, and rows >= N, are synthesised from cv::RNG(0x12345678) and Gram-Schmidt (for the 8x9 system that
+// synthesised 9th row IS the null vector the reference takes).  At holds N1 rows; W the N sorted singular values.
+template <int M, int N, int N1>
+__device__ __forceinline__ void svd_complete(float (&At)[N1 * M], const double (&W)[N]) {
+    const double minval = 1.17549435082228750797e-38;  // FLT_MIN
+    const float eps = 1.1920928955078125e-7f * 2;
     unsigned long long rng = 0x12345678ull;
+#pragma unroll
     for (int i = 0; i < N1; i++) {
-        sd = i < N ? W[i] : 0;
+        double sd = i < N ? W[i < N ? i : 0] : 0;
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
             const float val0 = (float)(1. / M);
+#pragma unroll
             for (int k = 0; k < M; k++) {
                 rng = (unsigned long long)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
-                float val = ((unsigned)rng & 256) != 0 ? val0 : -val0;
-                At[i * M + k] = val;
+                At[i * M + k] = ((unsigned)rng & 256) != 0 ? val0 : -val0;
             }
             for (int iter = 0; iter < 2; iter++) {
+#pragma unroll
                 for (int j = 0; j < i; j++) {
                     sd = 0;
+#pragma unroll
                     for (int k = 0; k < M; k++) sd += At[i * M + k] * At[j * M + k];
                     float asum = 0;
+#pragma unroll
                     for (int k = 0; k < M; k++) {
-                        float t = (float)(At[i * M + k] - sd * At[j * M + k]);
+                        const float t = (float)(At[i * M + k] - sd * At[j * M + k]);
                         At[i * M + k] = t;
                         asum += fabsf(t);
                     }
                     asum = asum > eps * 100 ? 1 / asum : 0;
+#pragma unroll
                     for (int k = 0; k < M; k++) At[i * M + k] *= asum;
                 }
             }
             sd = 0;
+#pragma unroll
             for (int k = 0; k < M; k++) {
-                float t = At[i * M + k];
+                const float t = At[i * M + k];
                 sd += (double)t * t;
             }
             sd = sqrt(sd);
         }
-        s = (float)(sd > minval ? 1 / sd : 0.);
+        const float s = (float)(sd > minval ? 1 / sd : 0.);
+#pragma unroll
         for (int k = 0; k < M; k++) At[i * M + k] *= s;
     }
 }
@@ -173,8 +216,11 @@ __device__ void jacobi_svd(float* At, float* Vt, double* W) {
 // cv::gemm small-matrix path for 3x3 CV_32F without transpose flags: float dot products, left to right.
 __device__ __forceinline__ void mul33(const float* A, const float* B, float* C) {
     float out[9];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) out[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
     for (int i = 0; i < 9; i++) C[i] = out[i];
 }
 
@@ -263,85 +309,125 @@ __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts,
     }
 }
 
-// K11: one hypothesis per lane.  geometry::computeFundamentalMat (utils.cpp:61-103) and computeHomographyMat
-// (utils.cpp:112-154) on the 8 normalised correspondences of the set, then the de-normalisation and scaling of
-// Initializer::findFundamentalMat / findHomographyMat (Initializer.cpp:336-345, 476-486).
-__global__ __launch_bounds__(64) void k_solve(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
-                                              const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
-                                              int iterations, float* __restrict__ F_all, float* __restrict__ H_all,
-                                              float* __restrict__ Hinv_all) {
+// K11F: one hypothesis per lane.  geometry::computeFundamentalMat (utils.cpp:61-103) on the 8 normalised
+// correspondences of the set, then the de-normalisation and scaling of Initializer::findFundamentalMat
+// (Initializer.cpp:336-345).
+__global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
+                                                const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
+                                                int iterations, float* __restrict__ F_all) {
     const int it = blockIdx.x * 64 + threadIdx.x;
     const int pair = blockIdx.y;
     if (it >= iterations) return;
     const float* pn = pts_n + (size_t)pair * n * 2;
     const float* rn = ref_n + (size_t)pair * n * 2;
     const uint32_t* set = sets8 + ((size_t)pair * iterations + it) * 8;
-    float u1[8], v1[8], u2[8], v2[8];
-    for (int j = 0; j < 8; j++) {
-        const uint32_t idx = set[j];
-        u2[j] = pn[2 * idx];
-        v2[j] = pn[2 * idx + 1];
-        u1[j] = rn[2 * idx];
-        v1[j] = rn[2 * idx + 1];
+    // 8x9 system used as is (rows = equations): N = 8 rows of length M = 9, completed to 9 rows
+    float At[81];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t idx = set[i];
+        const float u2 = pn[2 * idx], v2 = pn[2 * idx + 1], u1 = rn[2 * idx], v1 = rn[2 * idx + 1];
+        At[i * 9 + 0] = u2 * u1; At[i * 9 + 1] = u2 * v1; At[i * 9 + 2] = u2;
+        At[i * 9 + 3] = v2 * u1; At[i * 9 + 4] = v2 * v1; At[i * 9 + 5] = v2;
+        At[i * 9 + 6] = u1; At[i * 9 + 7] = v1; At[i * 9 + 8] = 1;
     }
+#pragma unroll
+    for (int k = 0; k < 9; k++) At[72 + k] = 0.f;
+    {
+        float(&A8)[72] = *reinterpret_cast<float(*)[72]>(&At[0]);
+        float no_v[1];
+        double W[8];
+        int perm[8];
+        jacobi_sweeps<9, 8, false>(A8, no_v, W);
+        svd_finish<9, 8, false, true>(A8, no_v, W, perm);
+        svd_complete<9, 8, 9>(At, W);
+    }
+    // Fpre = vt.row(8) reshaped 3x3; the second SVD works on its transpose
+    float B[9], V3[9];
+    double W3[3];
+    int perm3[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) B[j * 3 + i] = At[72 + i * 3 + j];
+    jacobi_sweeps<3, 3, true>(B, V3, W3);
+    svd_finish<3, 3, true, true>(B, V3, W3, perm3);
+    svd_complete<3, 3, 3>(B, W3);
     const float* T = T_all + (size_t)pair * 18;
     const float* refT = T + 9;
-    float At[144];
-    float Vt[81];
-    double W[9];
+    const float w0 = (float)W3[0], w1 = (float)W3[1];
+    float U[9], D[9] = {w0, 0, 0, 0, w1, 0, 0, 0, 0.f}, UD[9], Fn[9], tmp[9], Tt[9], F[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) U[j * 3 + i] = B[i * 3 + j];
+    mul33(U, D, UD);
+    mul33(UD, V3, Fn);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Tt[j * 3 + i] = T[i * 3 + j];
+    mul33(Tt, Fn, tmp);
+    mul33(tmp, refT, F);
+    if (fabs((double)F[8]) > 1e-8) scale33(F, 1.0 / F[8]);
     const size_t o = ((size_t)pair * iterations + it) * 9;
-    {
-        // 8x9 system used as is (rows = equations): N = 8 rows of length M = 9, completed to 9 rows
-        for (int i = 0; i < 8; i++) {
-            float* r = At + i * 9;
-            r[0] = u2[i] * u1[i]; r[1] = u2[i] * v1[i]; r[2] = u2[i];
-            r[3] = v2[i] * u1[i]; r[4] = v2[i] * v1[i]; r[5] = v2[i];
-            r[6] = u1[i]; r[7] = v1[i]; r[8] = 1;
-        }
-        jacobi_svd<9, 8, 9, true>(At, Vt, W);
-        // Fpre = vt.row(8) reshaped 3x3; second SVD works on its transpose
-        float Fpre[9], B[9], V3[9];
-        double W3[3];
-        for (int k = 0; k < 9; k++) Fpre[k] = At[8 * 9 + k];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) B[j * 3 + i] = Fpre[i * 3 + j];
-        jacobi_svd<3, 3, 3, true>(B, V3, W3);
-        float w0 = (float)W3[0], w1 = (float)W3[1];
-        float U[9], D[9] = {w0, 0, 0, 0, w1, 0, 0, 0, 0.f}, UD[9], Fn[9], tmp[9], Tt[9], F[9];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) U[j * 3 + i] = B[i * 3 + j];
-        mul33(U, D, UD);
-        mul33(UD, V3, Fn);
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) Tt[j * 3 + i] = T[i * 3 + j];
-        mul33(Tt, Fn, tmp);
-        mul33(tmp, refT, F);
-        if (fabs((double)F[8]) > 1e-8) scale33(F, 1.0 / F[8]);
-        for (int k = 0; k < 9; k++) F_all[o + k] = F[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) F_all[o + k] = F[k];
+}
+
+// K11H: one hypothesis per lane.  geometry::computeHomographyMat (utils.cpp:112-154), then the de-normalisation,
+// inverse and scaling of Initializer::findHomographyMat (Initializer.cpp:476-486).
+__global__ __launch_bounds__(64) void k_solve_h(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
+                                                const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
+                                                int iterations, float* __restrict__ H_all,
+                                                float* __restrict__ Hinv_all) {
+    const int it = blockIdx.x * 64 + threadIdx.x;
+    const int pair = blockIdx.y;
+    if (it >= iterations) return;
+    const float* pn = pts_n + (size_t)pair * n * 2;
+    const float* rn = ref_n + (size_t)pair * n * 2;
+    const uint32_t* set = sets8 + ((size_t)pair * iterations + it) * 8;
+    // the 16x9 system is transposed: N = 9 rows of length M = 16; only Vt is needed
+    float At[144], Vt[81];
+    double W[9];
+    int perm[9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t idx = set[i];
+        const float u2 = pn[2 * idx], v2 = pn[2 * idx + 1], u1 = rn[2 * idx], v1 = rn[2 * idx + 1];
+        const int c0 = 2 * i, c1 = 2 * i + 1;
+        At[0 * 16 + c0] = 0.0f; At[1 * 16 + c0] = 0.0f; At[2 * 16 + c0] = 0.0f;
+        At[3 * 16 + c0] = -u1; At[4 * 16 + c0] = -v1; At[5 * 16 + c0] = -1;
+        At[6 * 16 + c0] = v2 * u1; At[7 * 16 + c0] = v2 * v1; At[8 * 16 + c0] = v2;
+        At[0 * 16 + c1] = u1; At[1 * 16 + c1] = v1; At[2 * 16 + c1] = 1;
+        At[3 * 16 + c1] = 0.0f; At[4 * 16 + c1] = 0.0f; At[5 * 16 + c1] = 0.0f;
+        At[6 * 16 + c1] = -u2 * u1; At[7 * 16 + c1] = -u2 * v1; At[8 * 16 + c1] = -u2;
     }
-    {
-        // 16x9 system is transposed: N = 9 rows of length M = 16; only Vt is needed
-        for (int i = 0; i < 8; i++) {
-            const int c0 = 2 * i, c1 = 2 * i + 1;
-            At[0 * 16 + c0] = 0.0f; At[1 * 16 + c0] = 0.0f; At[2 * 16 + c0] = 0.0f;
-            At[3 * 16 + c0] = -u1[i]; At[4 * 16 + c0] = -v1[i]; At[5 * 16 + c0] = -1;
-            At[6 * 16 + c0] = v2[i] * u1[i]; At[7 * 16 + c0] = v2[i] * v1[i]; At[8 * 16 + c0] = v2[i];
-            At[0 * 16 + c1] = u1[i]; At[1 * 16 + c1] = v1[i]; At[2 * 16 + c1] = 1;
-            At[3 * 16 + c1] = 0.0f; At[4 * 16 + c1] = 0.0f; At[5 * 16 + c1] = 0.0f;
-            At[6 * 16 + c1] = -u2[i] * u1[i]; At[7 * 16 + c1] = -u2[i] * v1[i]; At[8 * 16 + c1] = -u2[i];
+    jacobi_sweeps<16, 9, true>(At, Vt, W);
+    svd_finish<16, 9, true, false>(At, Vt, W, perm);
+    // vt.row(8): the row the sort leaves last
+    float Hn[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Hn[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; r++)
+        if (perm[8] == r) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) Hn[k] = Vt[r * 9 + k];
         }
-        jacobi_svd<16, 9, 9, false>(At, Vt, W);
-        float Hn[9], Tinv[9], tmp[9], H[9], Hinv[9];
-        for (int k = 0; k < 9; k++) Hn[k] = Vt[8 * 9 + k];
-        inv33(T, Tinv);
-        mul33(Tinv, Hn, tmp);
-        mul33(tmp, refT, H);
-        inv33(H, Hinv);
-        if (fabs((double)H[8]) > 1e-8) scale33(H, 1.0 / H[8]);
-        for (int k = 0; k < 9; k++) {
-            H_all[o + k] = H[k];
-            Hinv_all[o + k] = Hinv[k];
-        }
+    const float* T = T_all + (size_t)pair * 18;
+    const float* refT = T + 9;
+    float Tinv[9], tmp[9], H[9], Hinv[9];
+    inv33(T, Tinv);
+    mul33(Tinv, Hn, tmp);
+    mul33(tmp, refT, H);
+    inv33(H, Hinv);
+    if (fabs((double)H[8]) > 1e-8) scale33(H, 1.0 / H[8]);
+    const size_t o = ((size_t)pair * iterations + it) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        H_all[o + k] = H[k];
+        Hinv_all[o + k] = Hinv[k];
     }
 }
 
