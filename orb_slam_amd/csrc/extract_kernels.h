@@ -135,14 +135,17 @@ __device__ __forceinline__ bool has_arc9(unsigned m) {
 
 // K3+K4a fused: FAST-9/16 score and 3x3 strict non-max suppression of one 64 x kTileH tile, never leaving LDS.
 //   phase 1  every pixel of the tile (plus a one-pixel ring for the suppression) takes the four-point compass test,
-//            evaluated on 64-bit lane masks with scalar logic; the pixels that pass (under a tenth) are queued;
+//            four pixels per lane from whole staged dwords, evaluated on 64-bit lane masks with scalar logic; the
+//            pixels that pass (under a tenth) are queued;
 //   phase 2  the queued pixels get their cornerScore with full lanes; the score itself says whether the
 //            nine-contiguous test holds;
-//   phase 3  suppression + border rule -> one ballot word per tile row; the score byte is stored only where a
-//            keypoint survives (all the emission reads).  DENSE also stores every score of the tile (tests).
+//   phase 3  suppression + border rule for the queued corners -> one mask word per tile row; the score byte is
+//            stored only where a keypoint survives (all the emission reads).  DENSE also stores every score of
+//            the tile (tests).
 constexpr int kFPitch = 80;              // LDS bytes per staged row: 64 + 2*4 halo + 3 alignment, rounded up
 constexpr int kFRows = kTileH + 8;
 constexpr int kSW = kTileW + 2, kSH = kTileH + 2;
+constexpr int kFGroups = 18;             // staged dwords per row that can hold a scored pixel (66 columns + alignment)
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     __shared__ unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
     __shared__ unsigned short queue[kSW * kSH];
+    __shared__ unsigned s_mask[2 * kTileH];
     __shared__ int q_count;
     uint8_t* t = (uint8_t*)t32;
     uint8_t* st = (uint8_t*)s32;
@@ -182,37 +186,53 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         t32[i] = *(const unsigned*)(fb + (size_t)ay * aw + ax);
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
+    if (tid < 2 * kTileH) s_mask[tid] = 0u;
     if (tid == 0) q_count = 0;
     __syncthreads();
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-    // phase 1: rows ys..ye of the scored rectangle, kSW columns from x0-1 each
-    const int n1 = empty ? 0 : (ye - ys) * kSW;
+    // phase 1: a lane takes the four pixels of one staged dword; rows ys..ye, kFGroups dwords across the tile + ring
+    const int n1 = empty ? 0 : (ye - ys) * kFGroups;
     for (int base = 0; base < n1; base += 256) {
-        const int idx = min(base + tid, n1 - 1);
-        const int r = idx / kSW, c = idx - r * kSW;
-        const int x = tl.x0 - 1 + c, y = ys + r;
-        const bool valid = base + tid < n1 && x >= xs && x < xe;
-        const unsigned long long vm = __ballot(valid);
-        if (vm == 0ull) continue;
-        const uint8_t* ctr = t + (y - tl.y0 + 4) * kFPitch + c + 3 + off;
-        const int v = ctr[0];
-        const int hi = v + threshold, lw = v - threshold;
+        const int item = min(base + tid, n1 - 1);
+        const int r = item / kFGroups, gq = item - r * kFGroups;
+        const int y = ys + r;
+        const int xg = tl.x0 - 4 - off + 4 * gq;          // level x of byte 0 of this dword
+        const unsigned* tr = t32 + (y - tl.y0 + 4) * (kFPitch / 4) + gq;
+        const unsigned C = tr[0], Lw = tr[-1], Rw = tr[1];
+        const unsigned P0 = tr[3 * (kFPitch / 4)], P8 = tr[-3 * (kFPitch / 4)];
+        const unsigned P4 = __builtin_amdgcn_alignbyte(Rw, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
         // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12): a pixel without two
         // adjacent compass points on the same side of the threshold band cannot be a corner
-        const int p0 = ctr[3 * kFPitch], p4 = ctr[3], p8 = ctr[-3 * kFPitch], p12 = ctr[-3];
-        const unsigned long long b0 = __ballot(p0 > hi), b4 = __ballot(p4 > hi), b8 = __ballot(p8 > hi),
-                                 b12 = __ballot(p12 > hi);
-        const unsigned long long d0 = __ballot(p0 < lw), d4 = __ballot(p4 < lw), d8 = __ballot(p8 < lw),
-                                 d12 = __ballot(p12 < lw);
-        const unsigned long long pass =
-            (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) & vm;
-        if (pass == 0ull) continue;
+        unsigned long long pass[4];
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = xg + j;
+            const bool valid = base + tid < n1 && x >= xs && x < xe;
+            const int v = (int)((C >> (8 * j)) & 255u);
+            const int hi = v + threshold, lw = v - threshold;
+            const int p0 = (int)((P0 >> (8 * j)) & 255u), p4 = (int)((P4 >> (8 * j)) & 255u);
+            const int p8 = (int)((P8 >> (8 * j)) & 255u), p12 = (int)((P12 >> (8 * j)) & 255u);
+            const unsigned long long b0 = __ballot(p0 > hi), b4 = __ballot(p4 > hi), b8 = __ballot(p8 > hi),
+                                     b12 = __ballot(p12 > hi);
+            const unsigned long long d0 = __ballot(p0 < lw), d4 = __ballot(p4 < lw), d8 = __ballot(p8 < lw),
+                                     d12 = __ballot(p12 < lw);
+            pass[j] = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) & __ballot(valid);
+            total += __popcll(pass[j]);
+        }
+        if (total == 0) continue;
         int qb = 0;
-        if (lane == 0) qb = atomicAdd(&q_count, __popcll(pass));
+        if (lane == 0) qb = atomicAdd(&q_count, total);
         qb = __builtin_amdgcn_readfirstlane(qb);
-        if ((pass >> lane) & 1ull)
-            queue[qb + __popcll(pass & ((1ull << lane) - 1ull))] = (unsigned short)((y - tl.y0 + 1) * kSW + c);
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((pass[j] >> lane) & 1ull)
+                queue[qb + __popcll(pass[j] & below)] =
+                    (unsigned short)((y - tl.y0 + 1) * kSW + (xg + j - tl.x0 + 1));
+            qb += __popcll(pass[j]);
+        }
     }
     __syncthreads();
     // phase 2: cornerScore of the queued pixels: max(threshold, best arc-of-9 minimum of |v - p|) - 1
@@ -245,22 +265,30 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         if (best > threshold) st[pos] = (uint8_t)(best - 1);  // an arc of nine clears the band <=> a corner
     }
     __syncthreads();
-    // phase 3: suppression, border rule, one mask word per tile row
-    for (int r = wv; r < kTileH; r += 4) {
-        const int y = tl.y0 + r, x = tl.x0 + lane;
-        if (y >= L.h) break;
-        const uint8_t* s = st + (r + 1) * kSW + lane + 1;
-        const int c = s[0];
-        bool kp = false;
-        if (c && level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo)
-            kp = c > s[1] && c > s[-1] && c > s[-kSW - 1] && c > s[-kSW] && c > s[-kSW + 1] && c > s[kSW - 1] &&
-                 c > s[kSW] && c > s[kSW + 1];
-        const unsigned long long w = __ballot(kp);
-        if (lane == 0) mk[(size_t)y * L.words_per_row] = w;
-        if (DENSE) {
-            if (x < L.w) sc[(size_t)r * aw + lane] = (uint8_t)c;
-        } else if (kp)
-            sc[(size_t)r * aw + lane] = (uint8_t)c;
+    // phase 3: suppression and border rule for the queued corners of the tile proper; bits gathered per tile row
+    for (int q = tid; q < nq; q += 256) {
+        const int pos = queue[q];
+        const int c = st[pos];
+        const int r = pos / kSW - 1, cc = pos - (r + 1) * kSW - 1;
+        if (c == 0 || r < 0 || r >= kTileH || cc < 0 || cc >= kTileW) continue;
+        const int y = tl.y0 + r, x = tl.x0 + cc;
+        if (!(level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo)) continue;
+        const uint8_t* s = st + pos;
+        if (c > s[1] && c > s[-1] && c > s[-kSW - 1] && c > s[-kSW] && c > s[-kSW + 1] && c > s[kSW - 1] &&
+            c > s[kSW] && c > s[kSW + 1]) {
+            atomicOr(&s_mask[2 * r + (cc >> 5)], 1u << (cc & 31));
+            if (!DENSE) sc[(size_t)r * aw + cc] = (uint8_t)c;
+        }
+    }
+    __syncthreads();
+    if (tid < kTileH && tl.y0 + tid < L.h)
+        mk[(size_t)(tl.y0 + tid) * L.words_per_row] =
+            (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
+    if (DENSE) {
+        for (int r = wv; r < kTileH; r += 4) {
+            const int y = tl.y0 + r, x = tl.x0 + lane;
+            if (y < L.h && x < L.w) sc[(size_t)r * aw + lane] = st[(r + 1) * kSW + lane + 1];
+        }
     }
 }
 
