@@ -75,14 +75,13 @@ def algorithmic_bytes(n_kp):
     per_kernel = {
         "gray": 3 * W * H + W * H,                      # read BGR, write level 0
         "resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, NLEVELS)),
-        "fast": 2 * P,                                  # read pyramid, write score map
-        "nms": P + P // 8,                              # read score map, write 1 bit / pixel
+        "fast": P + P // 8,                             # fused FAST + NMS: read pyramid, write 1 bit / pixel
         "emit": P // 8,                                 # read mask
         "harris": 2 * n_kp * (81 + 709),                # 9x9 + radius-15 disc per surviving candidate (~2x quota)
         "blur": 2 * P,                                  # read pyramid, write blurred pyramid
         "brief": n_kp * (512 + 32),                     # 512 samples + 32 descriptor bytes per keypoint
     }
-    frame_total = 3 * W * H + 4 * P + n_kp * (2 * 81 + 709 + 512)
+    frame_total = sum(per_kernel.values())
     return per_kernel, frame_total
 
 
@@ -231,8 +230,20 @@ def main():
     stage_avg["match_window"] = float(np.mean([a.elapsed_time(b) for a, b in match_ms]))
     dom = max((k for k in stage_avg if k in per_kernel), key=lambda k: stage_avg[k])
     achieved = per_kernel[dom] * B / (stage_avg[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
+    # HBM bytes per launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs of this command)
+    traffic = None
+    kernel_of = {"gray": "k_gray_level0", "resize": "k_resize_level4", "fast": "k_fast_nms", "emit": "k_emit",
+                 "harris": "k_harris_angle", "blur": "k_blur", "brief": "k_brief"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f).get(kernel_of[dom])
+        if pmc and pmc.get("frames_per_launch") == B:
+            traffic = pmc["traffic_bytes"] * (NLEVELS - 1 if dom == "resize" else 1)
+    except (OSError, ValueError, KeyError):
+        pass
+    roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": traffic,
+                "algorithmic_bytes_per_launch": per_kernel[dom] * B,
                 "stage_ms_per_batch": stage_avg, "algorithmic_bytes_per_frame": frame_bytes,
                 "device_ms_per_batch": float(sum(stage_avg.values()))}
 

@@ -62,7 +62,7 @@ struct orbx_extractor {
     int kp_cap = 0;    // final keypoints per frame
 
     DevBuf<uint8_t> d_in, d_atlas, d_score, d_blur, d_desc;
-    DevBuf<unsigned long long> d_mask;
+    DevBuf<MaskWord> d_mask;
     DevBuf<Cand> d_cand, d_packed;
     DevBuf<int> d_level_counts, d_thresholds, d_totals, d_offsets, d_kp_counts;
     DevBuf<orbx_keypoint> d_kp;

@@ -149,12 +149,13 @@ constexpr int kFGroups = 18;             // staged dwords per row that can hold 
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
-                                                  unsigned long long* __restrict__ mask, size_t atlas_bytes, Geom g,
+                                                  MaskWord* __restrict__ mask, size_t atlas_bytes, Geom g,
                                                   const Tile* __restrict__ tiles, int threshold, int frame0) {
     __shared__ unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
     __shared__ unsigned short queue[kSW * kSH];
     __shared__ unsigned s_mask[2 * kTileH];
+    __shared__ unsigned s_sc8[2 * kTileH];
     __shared__ int q_count;
     uint8_t* t = (uint8_t*)t32;
     uint8_t* st = (uint8_t*)s32;
@@ -169,11 +170,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     const int in = DENSE ? 3 : max(lo - 1, 3);
     const int xs = max(tl.x0 - 1, in), xe = min(tl.x0 + kTileW + 1, L.w - in);
     const int ys = max(tl.y0 - 1, in), ye = min(tl.y0 + kTileH + 1, L.h - in);
-    unsigned long long* mk = mask + (size_t)b * g.total_words + L.word_base + (tl.x0 >> 6);
+    MaskWord* mk = mask + (size_t)b * g.total_words + L.word_base + (tl.x0 >> 6);
     uint8_t* sc = score + (size_t)b * atlas_bytes + (size_t)(L.y + tl.y0) * aw + L.x + tl.x0;
     const bool empty = xs >= xe || ys >= ye || (!DENSE && !level_ok);
     if (empty && !DENSE) {
-        if (tid < kTileH && tl.y0 + tid < L.h) mk[(size_t)(tl.y0 + tid) * L.words_per_row] = 0ull;
+        if (tid < kTileH && tl.y0 + tid < L.h) mk[(size_t)(tl.y0 + tid) * L.words_per_row] = MaskWord{0ull, 0ull};
         return;
     }
     // stage the tile with a 4-pixel halo, aligned dwords (levels sit at least 32 pixels inside the atlas)
@@ -186,7 +187,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         t32[i] = *(const unsigned*)(fb + (size_t)ay * aw + ax);
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
-    if (tid < 2 * kTileH) s_mask[tid] = 0u;
+    if (tid < 2 * kTileH) {
+        s_mask[tid] = 0u;
+        s_sc8[tid] = 0u;
+    }
     if (tid == 0) q_count = 0;
     __syncthreads();
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -270,20 +274,37 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         const int pos = queue[q];
         const int c = st[pos];
         const int r = pos / kSW - 1, cc = pos - (r + 1) * kSW - 1;
-        if (c == 0 || r < 0 || r >= kTileH || cc < 0 || cc >= kTileW) continue;
-        const int y = tl.y0 + r, x = tl.x0 + cc;
-        if (!(level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo)) continue;
-        const uint8_t* s = st + pos;
-        if (c > s[1] && c > s[-1] && c > s[-kSW - 1] && c > s[-kSW] && c > s[-kSW + 1] && c > s[kSW - 1] &&
-            c > s[kSW] && c > s[kSW + 1]) {
-            atomicOr(&s_mask[2 * r + (cc >> 5)], 1u << (cc & 31));
-            if (!DENSE) sc[(size_t)r * aw + cc] = (uint8_t)c;
+        bool kp = false;
+        if (c != 0 && r >= 0 && r < kTileH && cc >= 0 && cc < kTileW) {
+            const int y = tl.y0 + r, x = tl.x0 + cc;
+            if (level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo) {
+                const uint8_t* s = st + pos;
+                kp = c > s[1] && c > s[-1] && c > s[-kSW - 1] && c > s[-kSW] && c > s[-kSW + 1] && c > s[kSW - 1] &&
+                     c > s[kSW] && c > s[kSW + 1];
+            }
         }
+        if (kp) atomicOr(&s_mask[2 * r + (cc >> 5)], 1u << (cc & 31));
+        else queue[q] = 0xffffu;
     }
     __syncthreads();
-    if (tid < kTileH && tl.y0 + tid < L.h)
-        mk[(size_t)(tl.y0 + tid) * L.words_per_row] =
-            (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
+    // the scores of the first eight keypoints of a row word travel with the word; later ones (rare) go to the plane
+    for (int q = tid; q < nq; q += 256) {
+        const int pos = queue[q];
+        if (pos == 0xffff) continue;
+        const int r = pos / kSW - 1, cc = pos - (r + 1) * kSW - 1;
+        const unsigned long long row = (unsigned long long)s_mask[2 * r] | ((unsigned long long)s_mask[2 * r + 1] << 32);
+        const int rank = __popcll(row & ((1ull << cc) - 1ull));
+        const unsigned c = st[pos];
+        if (rank < 8) atomicOr(&s_sc8[2 * r + (rank >> 2)], c << (8 * (rank & 3)));
+        else if (!DENSE) sc[(size_t)r * aw + cc] = (uint8_t)c;
+    }
+    __syncthreads();
+    if (tid < kTileH && tl.y0 + tid < L.h) {
+        MaskWord w;
+        w.bits = (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
+        w.scores = (unsigned long long)s_sc8[2 * tid] | ((unsigned long long)s_sc8[2 * tid + 1] << 32);
+        mk[(size_t)(tl.y0 + tid) * L.words_per_row] = w;
+    }
     if (DENSE) {
         for (int r = wv; r < kTileH; r += 4) {
             const int y = tl.y0 + r, x = tl.x0 + lane;
@@ -308,7 +329,7 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 // their exact rank, so the candidate list has the order cv::FAST emits.  Also builds the per-level histogram of
 // FAST scores and from it the score of the (2*quota)-th best corner: the value
 // KeyPointsFilter::retainBest(2*quota) keeps everything at or above.
-__global__ __launch_bounds__(1024) void k_emit(const unsigned long long* __restrict__ mask,
+__global__ __launch_bounds__(1024) void k_emit(const MaskWord* __restrict__ mask,
                                                const uint8_t* __restrict__ score, size_t atlas_bytes, Geom g,
                                                Cand* __restrict__ cand, int cap, int* __restrict__ level_counts,
                                                int* __restrict__ thresholds, int* __restrict__ totals) {
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(1024) void k_emit(const unsigned long long* __restr
     const int tid = threadIdx.x;
     for (int i = tid; i < kMaxLevels * 256; i += 1024) (&hist[0][0])[i] = 0;
     if (tid < kMaxLevels) lcount[tid] = 0;
-    const unsigned long long* mk = mask + (size_t)b * g.total_words;
+    const MaskWord* mk = mask + (size_t)b * g.total_words;
     const uint8_t* sc = score + (size_t)b * atlas_bytes;
     Cand* out = cand + (size_t)b * cap;
     const int lane = tid & 63, wv = tid >> 6;
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(1024) void k_emit(const unsigned long long* __restr
     int mine = 0;
     for (int base = w0; base < w1; base += 64) {
         const int word = base + lane;
-        mine += word < w1 ? __popcll(mk[word]) : 0;
+        mine += word < w1 ? __popcll(mk[word].bits) : 0;
     }
     mine = wave_scan_incl(mine);
     if (lane == 63) wave_tot[wv] = mine;
@@ -341,7 +362,8 @@ __global__ __launch_bounds__(1024) void k_emit(const unsigned long long* __restr
     }
     for (int base = w0; base < w1; base += 64) {
         const int word = base + lane;
-        unsigned long long m = word < w1 ? mk[word] : 0ull;
+        const MaskWord mw = word < w1 ? mk[word] : MaskWord{0ull, 0ull};
+        unsigned long long m = mw.bits;
         const int c = __popcll(m);
         const int incl = wave_scan_incl(c);
         int pos = running + incl - c;
@@ -354,11 +376,14 @@ __global__ __launch_bounds__(1024) void k_emit(const unsigned long long* __restr
             const int y = r / L.words_per_row;
             const int x0 = (r - y * L.words_per_row) * 64;
             atomicAdd(&lcount[l], c);
+            int rank = 0;
             while (m) {
                 const int bit = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const int x = x0 + bit;
-                const int s = sc[(size_t)(L.y + y) * g.atlas_w + L.x + x];
+                const int s = rank < 8 ? (int)((mw.scores >> (8 * rank)) & 255ull)
+                                       : (int)sc[(size_t)(L.y + y) * g.atlas_w + L.x + x];
+                rank++;
                 if (pos < cap) {
                     Cand cd;
                     cd.x = (uint16_t)x;

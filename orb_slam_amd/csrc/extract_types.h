@@ -71,4 +71,11 @@ struct Tile {
     int16_t x0, y0;
 };
 
+// One 64-pixel run of a level row after non-max suppression: a bit per keypoint and the FAST scores of the first
+// eight of them (lowest x first); a ninth or later keypoint of the run has its score in the score plane.
+struct MaskWord {
+    unsigned long long bits;
+    unsigned long long scores;
+};
+
 }  // namespace orbx

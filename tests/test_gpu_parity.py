@@ -121,6 +121,20 @@ def test_detect_edge_cases(oracle, ex1000):
     with pytest.raises(orbx.OrbxError) as e:
         ex1000.detect(img, capacity=10)
     assert e.value.status == orbx.CAPACITY
+    # a lattice of isolated dots with varying brightness: more than eight keypoints in one 64-pixel run of a row
+    # (the ninth and later scores of a run take the separate path), and many equal FAST scores
+    rng = np.random.default_rng(77)
+    dots = np.full((240, 320), 40, np.uint8)
+    dots[36:204:6, 36:284:5] = rng.integers(120, 255, dots[36:204:6, 36:284:5].shape).astype(np.uint8)
+    ex = orbx.Extractor(n_key_points=3000, level_pyramid=3, max_width=320, max_height=240)
+    p3 = oracle.orb_params(nfeatures=3000, nlevels=3)
+    got, want = ex.detect(dots), oracle.detect(p3, dots)
+    assert len(want) > 1000
+    assert np.array_equal(got, want.astype(orbx.KP_DTYPE))
+    k2, d2 = ex.compute(dots, got)
+    ok2, od2 = oracle.compute(p3, dots, want)
+    assert np.array_equal(k2, ok2.astype(orbx.KP_DTYPE)) and np.array_equal(d2, od2)
+    ex.close()
 
 
 def test_extract_batch_equals_per_frame(oracle, test_images):
