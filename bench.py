@@ -81,7 +81,7 @@ def algorithmic_bytes(n_kp):
         "blur": 2 * P,                                  # read pyramid, write blurred pyramid
         "brief": n_kp * (512 + 32),                     # 512 samples + 32 descriptor bytes per keypoint
     }
-    frame_total = sum(per_kernel.values())
+    frame_total = 3 * W * H + 4 * P + n_kp * (2 * 81 + 709 + 512)
     return per_kernel, frame_total
 
 

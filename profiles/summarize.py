@@ -16,7 +16,7 @@ import sys
 
 
 def short(name):
-    name = name.split("(")[0].replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     return name.split("::")[-1].split("<")[0]
 
 
