@@ -44,7 +44,7 @@ struct orbx_extractor {
     std::vector<Coef> coefs;
     std::vector<CoefX> coefx;
     std::vector<CoefY> coefy;
-    struct ResizePlan { int cx_off, cy_off, ax_begin, n_dwords; };
+    struct ResizePlan { int cx_off, cy_off, ax_begin, n_dwords; bool narrow; };
     ResizePlan rplan[kMaxLevels];
     DevBuf<CoefX> d_coefx;
     DevBuf<CoefY> d_coefy;
@@ -212,6 +212,7 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
         rp.ax_begin = x_first & ~3;
         rp.n_dwords = (x_last - rp.ax_begin + 3) / 4;
         rp.cx_off = (int)h->coefx.size();
+        rp.narrow = true;  // every group's left samples lie within 8 bytes of the group's aligned base
         for (int i = 0; i < rp.n_dwords * 4; i++) {
             const int ax = rp.ax_begin + i;
             CoefX c{0, 0};
@@ -222,6 +223,14 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
                 c.w1f = (uint16_t)((k.w1 & 0x1ff) | ((o1 != k.ofs) ? 0x4000 : 0) | 0x8000);
             }
             h->coefx.push_back(c);
+        }
+        for (int q = 0; q < rp.n_dwords; q++) {
+            int lo = 0x7fffffff, hi = -1;
+            for (int j = 0; j < 4; j++) {
+                const CoefX& c = h->coefx[rp.cx_off + 4 * q + j];
+                if (c.w1f & 0x8000) { lo = std::min(lo, (int)c.src_ax); hi = std::max(hi, (int)c.src_ax); }
+            }
+            if (hi >= 0 && hi - (lo & ~3) >= 8) rp.narrow = false;
         }
         rp.cy_off = (int)h->coefy.size();
         for (int ty = 0; ty < L.h + 2 * border; ty++) {
@@ -276,6 +285,21 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     return ORBX_OK;
 }
 
+void launch_resize(orbx_extractor* h, int l, int frames, hipStream_t s) {
+    const Geom& g = h->geom;
+    const orbx_extractor::ResizePlan& rp = h->rplan[l];
+    const int rows = g.L[l].h + 2 * g.border;
+    if (rp.narrow) {
+        dim3 grid(div_up(rp.n_dwords, 64), div_up(rows, 4 * kResizeRows), frames);
+        hipLaunchKernelGGL(k_resize_strip, grid, dim3(256), 0, s, h->d_atlas.p, h->atlas_bytes, g.atlas_w, g.L[l],
+                           g.border, h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
+    } else {
+        dim3 grid(div_up(rp.n_dwords, 64), div_up(rows, 4), frames);
+        hipLaunchKernelGGL(k_resize_level4, grid, dim3(256), 0, s, h->d_atlas.p, h->atlas_bytes, g.atlas_w, g.L[l],
+                           g.border, h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
+    }
+}
+
 // Pyramid + FAST + NMS + ordered emission + Harris/angle for `frames` device-resident images.
 orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int frames, size_t frame_stride, int w,
                              int hgt, int stride, int ch, bool fork_blur = false) {
@@ -294,10 +318,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     T.end(ST_GRAY, s);
     T.begin(ST_RESIZE, s);
     for (int l = 1; l < g.nlevels; l++) {
-        const orbx_extractor::ResizePlan& rp = h->rplan[l];
-        dim3 grid(div_up(rp.n_dwords, 64), div_up(g.L[l].h + 2 * border, 4), frames);
-        hipLaunchKernelGGL(k_resize_level4, grid, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l], border,
-                           h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
+        launch_resize(h, l, frames, s);
     }
     T.end(ST_RESIZE, s);
     T.begin(ST_FAST, s);
@@ -342,10 +363,7 @@ orbx_status run_pyramid(orbx_extractor* h, const uint8_t* d_images, int frames, 
     h->timer.end(ST_GRAY, s);
     h->timer.begin(ST_RESIZE, s);
     for (int l = 1; l < g.nlevels; l++) {
-        const orbx_extractor::ResizePlan& rp = h->rplan[l];
-        dim3 gr(div_up(rp.n_dwords, 64), div_up(g.L[l].h + 2 * border, 4), frames);
-        hipLaunchKernelGGL(k_resize_level4, gr, dim3(256), 0, s, h->d_atlas.p, A, g.atlas_w, g.L[l], border,
-                           h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
+        launch_resize(h, l, frames, s);
     }
     h->timer.end(ST_RESIZE, s);
     ORBX_HIP(hipGetLastError());
