@@ -63,6 +63,7 @@ struct orbx_extractor {
 
     DevBuf<uint8_t> d_in, d_atlas, d_score, d_blur, d_desc;
     DevBuf<MaskWord> d_mask;
+    DevBuf<Steer> d_steer;
     DevBuf<Cand> d_cand, d_packed;
     DevBuf<int> d_level_counts, d_thresholds, d_totals, d_offsets, d_kp_counts;
     DevBuf<orbx_keypoint> d_kp;
@@ -384,9 +385,12 @@ orbx_status run_describe_stage(orbx_extractor* h, int frames) {
                            h->d_blur.p, A, g, h->d_strips.p, (int)h->strips.size(), h->blur_taps);
         h->timer.end(ST_BLUR, s);
     }
+    ORBX_TRY(h->d_steer.ensure((size_t)h->kp_cap * frames));
     h->timer.begin(ST_BRIEF, s);
-    hipLaunchKernelGGL(k_brief, dim3(div_up(h->kp_cap, 8), frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A, g,
-                       h->d_kp.p, h->d_kp_counts.p, h->kp_cap, h->d_desc.p, h->d_pattern.p);
+    hipLaunchKernelGGL(k_steer, dim3(div_up(h->kp_cap, 256), frames), dim3(256), 0, s, g, h->d_kp.p, h->d_kp_counts.p,
+                       h->kp_cap, h->d_steer.p);
+    hipLaunchKernelGGL(k_brief, dim3(div_up(h->kp_cap, 8), frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A,
+                       g.atlas_w, h->d_steer.p, h->d_kp_counts.p, h->kp_cap, h->d_desc.p, h->d_pattern.p);
     h->timer.end(ST_BRIEF, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -545,7 +549,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_coefx.release(); h->d_coefy.release(); h->d_pattern.release();
     h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
-    h->d_mask.release(); h->d_cand.release(); h->d_packed.release();
+    h->d_mask.release(); h->d_steer.release(); h->d_cand.release(); h->d_packed.release();
     h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
     h->d_kp_counts.release(); h->d_kp.release();
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();

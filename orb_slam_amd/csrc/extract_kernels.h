@@ -930,39 +930,70 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
 
 struct BriefPattern { int8_t p[1024]; };
 
+// Steering of one keypoint for rBRIEF: cos / sin of the angle (evaluated in double, as cv::ORB does), the rounded
+// centre in its level, the level's place and size in the atlas.
+struct Steer {
+    float a, b;
+    int cx, cy;
+    int org;   // atlas offset of the level's pixel (0, 0)
+    int w, h;
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void k_steer(Geom g, const orbx_keypoint* __restrict__ kps,
+                                               const int* __restrict__ counts, int kp_cap, Steer* __restrict__ steer) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= counts[b] || i >= kp_cap) return;
+    const orbx_keypoint kp = kps[(size_t)b * kp_cap + i];
+    const LevelInfo L = g.L[kp.octave];
+    float angle = kp.angle;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    Steer s;
+    s.a = (float)cos((double)angle);
+    s.b = (float)sin((double)angle);
+    s.cx = __float2int_rn(kp.x * L.inv_scale);
+    s.cy = __float2int_rn(kp.y * L.inv_scale);
+    s.org = L.y * g.atlas_w + L.x;
+    s.w = L.w;
+    s.h = L.h;
+    s.pad = 0;
+    steer[(size_t)b * kp_cap + i] = s;
+}
+
 // K8: rotated BRIEF (cv::ORB computeOrbDescriptors, WTA_K = 2).  32 lanes per keypoint, one descriptor byte per
 // lane.  Samples inside the level come from the blurred plane; samples in the level's border come from the
 // un-blurred atlas, which is what cv::ORB reads there (it blurs level interiors in place).
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ blurred,
-                                               size_t atlas_bytes, Geom g, const orbx_keypoint* __restrict__ kps,
+                                               size_t atlas_bytes, int aw, const Steer* __restrict__ steer,
                                                const int* __restrict__ counts, int kp_cap,
                                                uint8_t* __restrict__ desc, const BriefPattern* __restrict__ pat) {
     const int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 5);
     const int lane = threadIdx.x & 31;
     const int b = blockIdx.y;
     if (idx >= counts[b] || idx >= kp_cap) return;
-    const orbx_keypoint kp = kps[(size_t)b * kp_cap + idx];
-    const LevelInfo L = g.L[kp.octave];
-    float angle = kp.angle;
-    angle *= (float)(3.14159265358979323846 / 180.f);
-    const float a = (float)cos((double)angle), bb = (float)sin((double)angle);
-    const int cx = __float2int_rn(kp.x * L.inv_scale), cy = __float2int_rn(kp.y * L.inv_scale);
-    const int aw = g.atlas_w;
-    const size_t fo = (size_t)b * atlas_bytes;
-    const int8_t* q = pat->p + lane * 32;
+    const uint4* sp = (const uint4*)(steer + (size_t)b * kp_cap + idx);
+    const uint4 s0 = sp[0], s1 = sp[1];
+    const float a = __uint_as_float(s0.x), bb = __uint_as_float(s0.y);
+    const int cx = (int)s0.z, cy = (int)s0.w, lw = (int)s1.y, lh = (int)s1.z;
+    const size_t org = (size_t)b * atlas_bytes + (size_t)(int)s1.x;
+    const int* q = (const int*)(pat->p + lane * 32);  // four signed bytes per test: x0, y0, x1, y1
     int val = 0;
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++, q += 4) {
-        const float x0 = q[0] * a - q[1] * bb, y0 = q[0] * bb + q[1] * a;
-        const float x1 = q[2] * a - q[3] * bb, y1 = q[2] * bb + q[3] * a;
+    for (int bit = 0; bit < 8; bit++) {
+        const int pq = q[bit];
+        const float px0 = (float)(int)(signed char)(pq & 0xff), py0 = (float)(int)(signed char)((pq >> 8) & 0xff);
+        const float px1 = (float)(int)(signed char)((pq >> 16) & 0xff), py1 = (float)(int)(signed char)(pq >> 24);
+        const float x0 = px0 * a - py0 * bb, y0 = px0 * bb + py0 * a;
+        const float x1 = px1 * a - py1 * bb, y1 = px1 * bb + py1 * a;
         const int sx0 = cx + __float2int_rn(x0), sy0 = cy + __float2int_rn(y0);
         const int sx1 = cx + __float2int_rn(x1), sy1 = cy + __float2int_rn(y1);
-        const bool in0 = (unsigned)sx0 < (unsigned)L.w && (unsigned)sy0 < (unsigned)L.h;
-        const bool in1 = (unsigned)sx1 < (unsigned)L.w && (unsigned)sy1 < (unsigned)L.h;
-        const size_t o0 = fo + (size_t)(L.y + sy0) * aw + L.x + sx0;
-        const size_t o1 = fo + (size_t)(L.y + sy1) * aw + L.x + sx1;
-        const int t0 = in0 ? blurred[o0] : atlas[o0];
-        const int t1 = in1 ? blurred[o1] : atlas[o1];
+        const bool in0 = (unsigned)sx0 < (unsigned)lw && (unsigned)sy0 < (unsigned)lh;
+        const bool in1 = (unsigned)sx1 < (unsigned)lw && (unsigned)sy1 < (unsigned)lh;
+        const uint8_t* src0 = in0 ? blurred : atlas;
+        const uint8_t* src1 = in1 ? blurred : atlas;
+        const int t0 = src0[org + (ptrdiff_t)sy0 * aw + sx0];
+        const int t1 = src1[org + (ptrdiff_t)sy1 * aw + sx1];
         val |= (int)(t0 < t1) << bit;
     }
     desc[((size_t)b * kp_cap + idx) * 32 + lane] = (uint8_t)val;
