@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ransac-pairs", type=int, default=1024)
+    ap.add_argument("--streams", type=int, default=2, help="independent batches in flight per GPU")
     args = ap.parse_args()
 
     import torch
@@ -140,12 +141,6 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    # one non-default stream for torch's plumbing AND the library's kernels (a NULL stream handle means "the
-    # handle's own stream" to orbx_*_set_stream)
-    tstream = torch.cuda.Stream(device=device)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-
     B = args.frames
     base = np.load(os.path.join(ROOT, "tests", "golden", "test_images.npz"))["bgr1"]
     frames, homs = make_sequence(torch, base, B, rank * B, device)
@@ -157,49 +152,80 @@ def main():
     bounds = (max(min(corners[0, 0], corners[2, 0]), 0.0), min(max(corners[1, 0], corners[3, 0]), float(W)),
               max(min(corners[0, 1], corners[1, 1]), 0.0), min(max(corners[2, 1], corners[3, 1]), float(H)))
     grid = orbx.make_grid(bounds)
-
-    ex = orbx.Extractor(n_key_points=NKP, level_pyramid=NLEVELS, max_width=W, max_height=H, max_batch=B,
-                        device=local_rank)
-    ex.set_frame_model(cam, grid)
-    ex.set_stream(stream)
-    mt = orbx.Matcher(device=local_rank)
-    mt.set_stream(stream)
-    _, sf, _, _, _ = ex.scale_tables()
-
     n_pairs = B - 1
     frame_idx = torch.arange(1, B, dtype=torch.int32, device=device)
     ref_idx = torch.arange(0, B - 1, dtype=torch.int32, device=device)
     # x_f = H_f H_{f-1}^-1 x_{f-1}: the known inter-frame map stands in for pose + depth of the map points
     rel = torch.from_numpy(np.stack([homs[f] @ np.linalg.inv(homs[f - 1]) for f in range(1, B)])
                            .astype(np.float32)).to(device)
-    d_matched = torch.empty((n_pairs, CAP), dtype=torch.int32, device=device)
-    d_dist = torch.empty((n_pairs, CAP), dtype=torch.int32, device=device)
-    d_nm = torch.zeros(n_pairs, dtype=torch.int32, device=device)
-    ncell = grid.grid_cols * grid.grid_rows
+    torch.cuda.synchronize()
 
     stage_ms = {}
     match_ms = []
 
-    def step(record=False):
-        ex.extract_batch(frames.data_ptr(), B, W * H * 3, W, H, W * 3, 3, CAP, to_host=False)
-        if record:
-            for k, v in ex.last_timings().items():
-                stage_ms.setdefault(k, []).append(v)
-        kp_ptr, desc_ptr, cnt_ptr, cap = ex.device_results()
-        cs_ptr, ci_ptr = ex.device_grid()
-        kp = torch.as_tensor(DevView(kp_ptr, (B, cap, 7), "<f4"), device=device)
-        xy1 = torch.cat([kp[:-1, :, 0:2], torch.ones((B - 1, cap, 1), device=device)], 2)
-        q = torch.bmm(xy1, rel.transpose(1, 2))
-        proj = (q[:, :, :2] / q[:, :, 2:]).contiguous()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        mt.match_projection_frame_batch(grid, n_pairs, frame_idx.data_ptr(), ref_idx.data_ptr(), kp_ptr, desc_ptr,
-                                        cnt_ptr, cap, cs_ptr, ci_ptr, 0, proj.data_ptr(), 0, sf, 0, RADIUS, True,
-                                        d_matched.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr())
-        e1.record()
-        if record:
-            match_ms.append((e0, e1))
+    class Pipeline:
+        """One in-flight batch: its own HIP stream (torch's plumbing and the library's kernels share it; a NULL
+        stream handle means "the handle's own stream" to orbx_*_set_stream), extractor, matcher and outputs.
+        Batches are independent, so several pipelines keep the GPU busy while one of them sits in a
+        latency-bound kernel (ordered emission, selection, the greedy resolve) or in its end-of-batch hand-off."""
+
+        def __init__(self):
+            self.tstream = torch.cuda.Stream(device=device)
+            self.ex = orbx.Extractor(n_key_points=NKP, level_pyramid=NLEVELS, max_width=W, max_height=H, max_batch=B,
+                                     device=local_rank)
+            self.ex.set_frame_model(cam, grid)
+            self.ex.set_stream(self.tstream.cuda_stream)
+            self.mt = orbx.Matcher(device=local_rank)
+            self.mt.set_stream(self.tstream.cuda_stream)
+            self.sf = self.ex.scale_tables()[1]
+            self.d_matched = torch.empty((n_pairs, CAP), dtype=torch.int32, device=device)
+            self.d_dist = torch.empty((n_pairs, CAP), dtype=torch.int32, device=device)
+            self.d_nm = torch.zeros(n_pairs, dtype=torch.int32, device=device)
+
+        def step(self, record=False):
+            ex, mt = self.ex, self.mt
+            with torch.cuda.stream(self.tstream):
+                ex.extract_batch(frames.data_ptr(), B, W * H * 3, W, H, W * 3, 3, CAP, to_host=False)
+                if record:
+                    for k, v in ex.last_timings().items():
+                        stage_ms.setdefault(k, []).append(v)
+                kp_ptr, desc_ptr, cnt_ptr, cap = ex.device_results()
+                cs_ptr, ci_ptr = ex.device_grid()
+                kp = torch.as_tensor(DevView(kp_ptr, (B, cap, 7), "<f4"), device=device)
+                xy1 = torch.cat([kp[:-1, :, 0:2], torch.ones((B - 1, cap, 1), device=device)], 2)
+                q = torch.bmm(xy1, rel.transpose(1, 2))
+                proj = (q[:, :, :2] / q[:, :, 2:]).contiguous()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                mt.match_projection_frame_batch(grid, n_pairs, frame_idx.data_ptr(), ref_idx.data_ptr(), kp_ptr,
+                                                desc_ptr, cnt_ptr, cap, cs_ptr, ci_ptr, 0, proj.data_ptr(), 0, self.sf,
+                                                0, RADIUS, True, self.d_matched.data_ptr(), self.d_dist.data_ptr(),
+                                                self.d_nm.data_ptr())
+                e1.record()
+                self.tstream.synchronize()  # the batch's results are complete when step() returns
+                if record:
+                    match_ms.append((e0, e1))
+
+    pipes = [Pipeline() for _ in range(max(1, args.streams))]
+
+    def run_steps(n, record):
+        """n steps in all, dealt round-robin to the pipelines; each pipeline is driven by its own host thread
+        (the library calls release the GIL)."""
+        import threading
+        if len(pipes) == 1:
+            for _ in range(n):
+                pipes[0].step(record)
+            return
+        def work(pi):
+            torch.cuda.set_device(local_rank)
+            for _ in range(pi, n, len(pipes)):
+                pipes[pi].step(record)
+        th = [threading.Thread(target=work, args=(pi,)) for pi in range(len(pipes))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
 
     def barrier():
         torch.cuda.synchronize()
@@ -207,12 +233,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup * len(pipes), False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(record=True)
+    run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -220,6 +244,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    ex, d_nm = pipes[0].ex, pipes[0].d_nm
+    stream = pipes[0].tstream.cuda_stream
+    torch.cuda.set_stream(pipes[0].tstream)
     mean_matches = float(d_nm.float().mean().item())
     mean_kp = float(torch.as_tensor(DevView(ex.device_results()[2], (B,), "<i4"), device=device).float().mean().item())
     total_frames = world * B * args.steps
@@ -306,7 +333,8 @@ def main():
             "config": {"workload": "TUM-fr1-like monocular 640x480 BGR sequence (homography walk of the reference "
                                    "test image + noise), 1000 kp, 8 levels x1.2: per-frame extract (detect, "
                                    "undistort, 64x64 grid, compute) + windowed match (radius 15) to the previous frame",
-                       "frames_per_gpu_per_step": B, "mean_keypoints": mean_kp, "mean_window_matches": mean_matches,
+                       "frames_per_gpu_per_step": B, "batches_in_flight": len(pipes), "mean_keypoints": mean_kp,
+                       "mean_window_matches": mean_matches,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roofline, "ransac": ransac, "cpu_baseline": cpu,
         }
