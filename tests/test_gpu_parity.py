@@ -440,3 +440,38 @@ def test_wave_parallel_retain_best_matches_libstdcxx(oracle):
         a = orbx.selftest_retain_best_device(keys, npts)
         b = oracle.retain_best(keys, npts)
         assert np.array_equal(a, b), (len(keys), npts)
+
+
+def test_4k_extraction_bit_exact(oracle):
+    """3840x2160 gray frames, 8000 keypoints, 12 levels: single-frame detect / compute and the batch path (whose
+    device selection does not hold this many candidates and hands over to the host selection) against the oracle."""
+    import torch
+    w, h = 3840, 2160
+    rng = np.random.default_rng(41)
+    frames = []
+    for f in range(2):
+        img = np.full((h, w), 100, np.float32)
+        for _ in range(6000):
+            x0, y0 = rng.integers(0, w), rng.integers(0, h)
+            ww, hh = rng.integers(3, 400), rng.integers(3, 300)
+            img[y0:y0 + hh, x0:x0 + ww] = rng.integers(0, 256)
+        img += rng.normal(0, 2.5, img.shape)
+        frames.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    p = oracle.orb_params(nfeatures=8000, nlevels=12)
+    ex = orbx.Extractor(n_key_points=8000, level_pyramid=12, max_width=w, max_height=h, max_batch=2)
+    ora = []
+    for img in frames:
+        ok_ = oracle.detect(p, img)
+        ora.append((ok_,) + tuple(oracle.compute(p, img, ok_)))
+    k = ex.detect(frames[0], capacity=12000)
+    assert len(k) > 7000 and np.array_equal(k, ora[0][0].astype(orbx.KP_DTYPE))
+    k2, d2 = ex.compute(frames[0], k)
+    assert np.array_equal(k2, ora[0][1].astype(orbx.KP_DTYPE)) and np.array_equal(d2, ora[0][2])
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, 9000)
+    for f in range(2):
+        assert counts[f] == len(ora[f][1])
+        assert np.array_equal(kps[f, :counts[f]], ora[f][1].astype(orbx.KP_DTYPE))
+        assert np.array_equal(desc[f, :counts[f]], ora[f][2])
+    ex.close()
