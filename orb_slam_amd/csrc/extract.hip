@@ -286,6 +286,16 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     return ORBX_OK;
 }
 
+// Launch shape of k_gray_level0: x covers the larger of its two regions (interior 16-pixel groups, edge pixels).
+dim3 gray_grid(const Geom& g, int w, int hgt, int frames) {
+    const int border = g.border, rx = g.L[0].x;
+    const int ax_begin = (rx - border) & ~15;
+    const int nq = (rx + w + border - ax_begin + 15) >> 4;
+    const int n_in = std::max(((rx + w - ax_begin) >> 4) - ((rx - ax_begin + 15) >> 4), 0);
+    const int per_row = std::max(n_in, (nq - n_in) * 16);
+    return dim3(div_up(per_row * (hgt + 2 * border), 256), 2, frames);
+}
+
 void launch_resize(orbx_extractor* h, int l, int frames, hipStream_t s) {
     const Geom& g = h->geom;
     const orbx_extractor::ResizePlan& rp = h->rplan[l];
@@ -312,7 +322,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     const int border = g.border;
     T.begin(ST_GRAY, s);
     {
-        dim3 grid(div_up(div_up(w + 2 * border + 3, 4), 64), div_up(hgt + 2 * border, 4), frames);
+        dim3 grid = gray_grid(g, w, hgt, frames);
         hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch,
                            h->d_atlas.p, A, g.atlas_w, g.L[0].x, g.L[0].y, border);
     }
@@ -358,7 +368,7 @@ orbx_status run_pyramid(orbx_extractor* h, const uint8_t* d_images, int frames, 
     size_t A = h->atlas_bytes;
     const int border = g.border;
     h->timer.begin(ST_GRAY, s);
-    dim3 grid(div_up(div_up(w + 2 * border + 3, 4), 64), div_up(hgt + 2 * border, 4), frames);
+    dim3 grid = gray_grid(g, w, hgt, frames);
     hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch, h->d_atlas.p,
                        A, g.atlas_w, g.L[0].x, g.L[0].y, border);
     h->timer.end(ST_GRAY, s);

@@ -29,42 +29,68 @@ __device__ __forceinline__ unsigned gray_of(unsigned b, unsigned g, unsigned r) 
     return (b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14;
 }
 
-// K1: BGR/gray -> level 0 of the atlas including its reflect-101 border, four atlas pixels per lane.
+// K1: BGR/gray -> level 0 of the atlas including its reflect-101 border, sixteen atlas pixels per lane (48 source
+// bytes in three 16-byte loads, one 16-byte store).
 // cv::cvtColor(BGR2GRAY) 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14.
+__device__ __forceinline__ uint4 load_u128_any(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+__device__ __forceinline__ unsigned gray4(unsigned w0, unsigned w1, unsigned w2) {  // 12 BGR bytes -> 4 gray bytes
+    return gray_of(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u) |
+           gray_of(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u) << 8 |
+           gray_of((w1 >> 16) & 255u, w1 >> 24, w2 & 255u) << 16 |
+           gray_of((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24) << 24;
+}
+
+// blockIdx.y = 0: the 16-pixel groups that lie wholly inside the image (one 16-byte store per lane);
+// blockIdx.y = 1: the groups that touch the reflected border columns, one pixel per lane.
 __global__ __launch_bounds__(256) void k_gray_level0(const uint8_t* __restrict__ img, size_t frame_stride, int w, int h,
                                                      int stride, int ch, uint8_t* __restrict__ atlas,
                                                      size_t atlas_bytes, int aw, int rx, int ry, int border) {
-    const int q = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ty = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
-    const int ax_begin = (rx - border) & ~3;
-    const int ax = ax_begin + 4 * q;             // first of this lane's four atlas columns
+    const int ax_begin = (rx - border) & ~15;
     const int x_first = rx - border, x_last = rx + w + border;
-    if (ax >= x_last || ty >= h + 2 * border) return;
-    const int sy = reflect101(ty - border, h);
-    const uint8_t* row = img + (size_t)b * frame_stride + (size_t)sy * stride;
-    uint8_t* d = atlas + (size_t)b * atlas_bytes + (size_t)(ry - border + ty) * aw + ax;
-    const int sx = ax - rx;
-    if (sx >= 0 && sx + 3 < w) {  // interior: 4 (gray) or 12 (BGR) contiguous source bytes
-        unsigned out;
-        if (ch == 1) out = load_u32_any(row + sx);
+    const int nq = (x_last - ax_begin + 15) >> 4;            // 16-pixel groups per row
+    const int q_in0 = (rx - ax_begin + 15) >> 4;             // first group with all pixels at sx >= 0
+    const int q_in1 = (rx + w - ax_begin) >> 4;              // one past the last group with all pixels at sx < w
+    const int n_in = max(q_in1 - q_in0, 0);
+    const int rows = h + 2 * border;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const uint8_t* frame = img + (size_t)b * frame_stride;
+    uint8_t* plane = atlas + (size_t)b * atlas_bytes;
+    if (blockIdx.y == 0) {
+        if (n_in == 0) return;
+        const int ty = item / n_in, q = q_in0 + item - ty * n_in;
+        if (ty >= rows) return;
+        const int ax = ax_begin + 16 * q, sx = ax - rx;
+        const uint8_t* row = frame + (size_t)reflect101(ty - border, h) * stride;
+        uint8_t* d = plane + (size_t)(ry - border + ty) * aw + ax;
+        uint4 out;
+        if (ch == 1) out = load_u128_any(row + sx);
         else {
             const uint8_t* s = row + (size_t)sx * 3;
-            const unsigned w0 = load_u32_any(s), w1 = load_u32_any(s + 4), w2 = load_u32_any(s + 8);
-            out = gray_of(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u) |
-                  gray_of(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u) << 8 |
-                  gray_of((w1 >> 16) & 255u, w1 >> 24, w2 & 255u) << 16 |
-                  gray_of((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24) << 24;
+            const uint4 v0 = load_u128_any(s), v1 = load_u128_any(s + 16), v2 = load_u128_any(s + 32);
+            out.x = gray4(v0.x, v0.y, v0.z);
+            out.y = gray4(v0.w, v1.x, v1.y);
+            out.z = gray4(v1.z, v1.w, v2.x);
+            out.w = gray4(v2.y, v2.z, v2.w);
         }
-        *(unsigned*)d = out;
+        if (((aw | ax) & 15) == 0) *(uint4*)d = out;
+        else __builtin_memcpy(d, &out, 16);
         return;
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (ax + j < x_first || ax + j >= x_last) continue;
-        const uint8_t* s = row + (size_t)reflect101(sx + j, w) * ch;
-        d[j] = (uint8_t)(ch == 1 ? s[0] : gray_of(s[0], s[1], s[2]));
-    }
+    const int n_edge = (nq - n_in) * 16;                     // edge pixels per row
+    if (n_edge == 0) return;
+    const int ty = item / n_edge, e = item - ty * n_edge;
+    if (ty >= rows) return;
+    const int left = q_in0 * 16;                             // edge pixels left of the interior groups
+    const int ax = ax_begin + (e < left ? e : e - left + q_in1 * 16);
+    if (ax < x_first || ax >= x_last) return;
+    const uint8_t* s = frame + (size_t)reflect101(ty - border, h) * stride + (size_t)reflect101(ax - rx, w) * ch;
+    plane[(size_t)(ry - border + ty) * aw + ax] = (uint8_t)(ch == 1 ? s[0] : gray_of(s[0], s[1], s[2]));
 }
 
 // K2 (dword-wise): level l from level l-1 by cv::resize(INTER_LINEAR_EXACT), border included.  A lane produces four
