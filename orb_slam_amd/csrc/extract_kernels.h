@@ -924,22 +924,33 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
     const size_t fo = (size_t)blockIdx.y * atlas_bytes;
     const uint8_t* src = atlas + fo + (size_t)(L.y + y0 - 3) * aw + ax;
     uint8_t* dst = blurred + fo + (size_t)(L.y + y0) * aw + ax;
+    // Straight-line code: every row load is unconditional (row index clamped into the strip's own rows, whose
+    // results are then simply not stored), so the loads of later rows are in flight while earlier rows are filtered.
+    struct Row3 { unsigned lft, c, rgt; };
+    auto load_row = [&](int r) {
+        Row3 v;
+        __builtin_memcpy(&v, src + (size_t)min(r, rows + 5) * aw - 4, 12);
+        return v;
+    };
+    constexpr int kBlurAhead = 4;
+    Row3 pf[kBlurAhead];
+#pragma unroll
+    for (int r = 0; r < kBlurAhead; r++) pf[r] = load_row(r);
     unsigned h[7][4];
 #pragma unroll
     for (int r = 0; r < kStripRows + 6; r++) {
-        if (r < rows + 6) {
-            const unsigned* p = (const unsigned*)(src + (size_t)r * aw);
-            const unsigned lft = p[-1], c = p[0], rgt = p[1];
-            unsigned* hr = h[r % 7];
-            hr[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 1), bt.wa,
-                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 1), bt.wb, 0u, false), false);
-            hr[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 2), bt.wa,
-                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 2), bt.wb, 0u, false), false);
-            hr[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 3), bt.wa,
-                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 3), bt.wb, 0u, false), false);
-            hr[3] = __builtin_amdgcn_udot4(c, bt.wa, __builtin_amdgcn_udot4(rgt, bt.wb, 0u, false), false);
-        }
-        if (r >= 6 && r - 6 < rows) {
+        const Row3 cur = pf[r % kBlurAhead];
+        if (r + kBlurAhead < kStripRows + 6) pf[r % kBlurAhead] = load_row(r + kBlurAhead);
+        const unsigned lft = cur.lft, c = cur.c, rgt = cur.rgt;
+        unsigned* hr = h[r % 7];
+        hr[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 1), bt.wa,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 1), bt.wb, 0u, false), false);
+        hr[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 2), bt.wa,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 2), bt.wb, 0u, false), false);
+        hr[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, lft, 3), bt.wa,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 3), bt.wb, 0u, false), false);
+        hr[3] = __builtin_amdgcn_udot4(c, bt.wa, __builtin_amdgcn_udot4(rgt, bt.wb, 0u, false), false);
+        if (r >= 6) {
             unsigned out = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -949,7 +960,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
                                    bt.k[0] * (h[(r - 6) % 7][j] + h[r % 7][j]);
                 out |= min((v + (1u << 15)) >> 16, 255u) << (8 * j);
             }
-            *(unsigned*)(dst + (size_t)(r - 6) * aw) = out;
+            if (r - 6 < rows) *(unsigned*)(dst + (size_t)(r - 6) * aw) = out;
         }
     }
 }
