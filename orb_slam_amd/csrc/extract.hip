@@ -238,6 +238,16 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
             const Coef& k = h->coefs[L.coef_y + refl(ty - border, L.h)];
             h->coefy.push_back(CoefY{S.y + k.ofs, S.y + std::min(k.ofs + 1, S.h - 1), k.w1});
         }
+        // the strip kernel parks at most kResizeSrcRows filtered source rows per block of kResizeRows output rows
+        for (int t0 = 0; t0 < L.h + 2 * border; t0 += kResizeRows) {
+            int lo = 0x7fffffff, hi = -1;
+            for (int ty = t0; ty < std::min(t0 + kResizeRows, L.h + 2 * border); ty++) {
+                const CoefY& c = h->coefy[rp.cy_off + ty];
+                lo = std::min(lo, std::min(c.row0, c.row1));
+                hi = std::max(hi, std::max(c.row0, c.row1));
+            }
+            if (hi - lo + 1 > kResizeSrcRows) rp.narrow = false;
+        }
     }
     g.total_words = words;
     g.total_tiles = (int)h->tiles.size();

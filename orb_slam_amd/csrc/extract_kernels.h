@@ -149,43 +149,37 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ atl
     }
 }
 
-// K2 (strip form, for scale factors whose four-pixel source span fits two dwords): a wavefront walks kResizeRows
-// output rows of a 256-pixel-wide column strip.  Everything that depends only on x - byte selectors, weights,
-// clamp mask - is set up once per lane; per SOURCE row the lane loads three dwords, lines up the four left and four
-// right samples with v_perm and forms the four horizontal sums (Q8) with 16-bit dot products; the two source rows
-// of an output row are kept from one output row to the next, so a source row is filtered once, not twice.
-constexpr int kResizeRows = 16;
-
-struct HRow { unsigned h[4]; };
-
-__device__ __forceinline__ HRow resize_hrow(const uint8_t* fb, int row, int aw, int base, unsigned sel, unsigned stepmask,
-                                            const unsigned (&wgt)[4]) {
-    const unsigned* p = (const unsigned*)(fb + (size_t)row * aw + base);
-    const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
-    const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, 1), e1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
-    const unsigned A4 = __builtin_amdgcn_perm(d1, d0, sel);
-    unsigned B4 = __builtin_amdgcn_perm(e1, e0, sel);
-    B4 = (B4 & stepmask) | (A4 & ~stepmask);
-    HRow r;
-    // (a_j | b_j << 16) . (wx0_j | wx1_j << 16)
-    const unsigned ab0 = __builtin_amdgcn_perm(B4, A4, 0x0c040c00u), ab1 = __builtin_amdgcn_perm(B4, A4, 0x0c050c01u);
-    const unsigned ab2 = __builtin_amdgcn_perm(B4, A4, 0x0c060c02u), ab3 = __builtin_amdgcn_perm(B4, A4, 0x0c070c03u);
-    r.h[0] = (ab0 & 0xffffu) * (wgt[0] & 0xffffu) + (ab0 >> 16) * (wgt[0] >> 16);
-    r.h[1] = (ab1 & 0xffffu) * (wgt[1] & 0xffffu) + (ab1 >> 16) * (wgt[1] >> 16);
-    r.h[2] = (ab2 & 0xffffu) * (wgt[2] & 0xffffu) + (ab2 >> 16) * (wgt[2] >> 16);
-    r.h[3] = (ab3 & 0xffffu) * (wgt[3] & 0xffffu) + (ab3 >> 16) * (wgt[3] >> 16);
-    return r;
-}
+// K2 (strip form, for scale factors whose four-pixel source span fits two dwords and whose kResizeRows output rows
+// draw on at most kResizeSrcRows source rows): a wavefront produces kResizeRows output rows of a 256-pixel-wide
+// column strip.  Everything that depends only on x - byte selectors, weights, clamp mask - is set up once per lane.
+// Pass A filters every source row of the block horizontally, all row loads in flight together: three dwords per
+// lane, the four left and four right samples lined up with v_perm, four Q8 sums packed into two dwords and parked
+// in the wavefront's LDS slice.  Pass B blends two parked rows per output row.  A source row is filtered once per
+// block, not once per output row that uses it.
+constexpr int kResizeRows = 8;
+constexpr int kResizeSrcRows = 12;
 
 __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw,
                                                       LevelInfo dst, int border, const CoefX* __restrict__ cxs,
                                                       const CoefY* __restrict__ cys, int ax_begin, int n_dwords) {
-    const int dc = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ uint2 s_h[4][kResizeSrcRows][64];
+    const int lane = threadIdx.x & 63;
+    const int dc = blockIdx.x * 64 + lane;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows = dst.h + 2 * border;
     const int ty0 = (blockIdx.y * 4 + wv) * kResizeRows;
-    if (dc >= n_dwords || ty0 >= rows) return;
-    const uint4 raw = *(const uint4*)(cxs + dc * 4);
+    if (ty0 >= rows) return;
+    const int ty1 = min(ty0 + kResizeRows, rows);
+    // source rows of the block (uniform): [r_lo, r_hi]
+    int r_lo = 0x7fffffff, r_hi = -1;
+    for (int ty = ty0; ty < ty1; ty++) {
+        const CoefY cy = cys[ty];
+        r_lo = min(r_lo, min(cy.row0, cy.row1));
+        r_hi = max(r_hi, max(cy.row0, cy.row1));
+    }
+    const int n_src = r_hi - r_lo + 1;
+    const bool live = dc < n_dwords;
+    const uint4 raw = *(const uint4*)(cxs + (live ? dc : 0) * 4);
     const unsigned cw[4] = {raw.x, raw.y, raw.z, raw.w};
     int sx[4];
     bool ok[4];
@@ -198,35 +192,53 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
         const unsigned w1 = f & 0x1ffu;
         wgt[j] = (256u - w1) | (w1 << 16);
         if ((f >> 14) & 1u) stepmask |= 0xffu << (8 * j);
-        ok[j] = (f >> 15) != 0;
+        ok[j] = live && (f >> 15) != 0;
         if (ok[j]) lo = min(lo, sx[j]);
     }
-    if (lo == 0x7fffffff) return;
-    const int base = lo & ~3;
+    const bool any = lo != 0x7fffffff;
+    const int base = any ? lo & ~3 : 0;
     unsigned sel = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) sel |= (unsigned)(ok[j] ? sx[j] - base : 0) << (8 * j);
     uint8_t* fb = atlas + (size_t)blockIdx.z * atlas_bytes;
+    // pass A
+    struct Row3 { unsigned d0, d1, d2; };
+    Row3 src[kResizeSrcRows];
+#pragma unroll
+    for (int k = 0; k < kResizeSrcRows; k++)
+        __builtin_memcpy(&src[k], fb + (size_t)min(r_lo + k, r_hi) * aw + base, 12);
+#pragma unroll
+    for (int k = 0; k < kResizeSrcRows; k++) {
+        if (k < n_src) {
+            const unsigned d0 = src[k].d0, d1 = src[k].d1, d2 = src[k].d2;
+            const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, 1), e1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+            const unsigned A4 = __builtin_amdgcn_perm(d1, d0, sel);
+            unsigned B4 = __builtin_amdgcn_perm(e1, e0, sel);
+            B4 = (B4 & stepmask) | (A4 & ~stepmask);
+            unsigned hh[4];
+            // (a_j | b_j << 16) . (wx0_j | wx1_j << 16)
+            const unsigned ab[4] = {__builtin_amdgcn_perm(B4, A4, 0x0c040c00u), __builtin_amdgcn_perm(B4, A4, 0x0c050c01u),
+                                    __builtin_amdgcn_perm(B4, A4, 0x0c060c02u), __builtin_amdgcn_perm(B4, A4, 0x0c070c03u)};
+#pragma unroll
+            for (int j = 0; j < 4; j++) hh[j] = (ab[j] & 0xffffu) * (wgt[j] & 0xffffu) + (ab[j] >> 16) * (wgt[j] >> 16);
+            s_h[wv][k][lane] = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));  // each sum <= 255 * 256
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!any) return;
+    // pass B
     const bool whole = ok[0] && ok[1] && ok[2] && ok[3];
-    HRow A, B;
-    int idx_a = -1, idx_b = -1;
-    const int ty1 = min(ty0 + kResizeRows, rows);
     for (int ty = ty0; ty < ty1; ty++) {
         const CoefY cy = cys[ty];
-        if (cy.row0 != idx_a) {
-            if (cy.row0 == idx_b) A = B;
-            else A = resize_hrow(fb, cy.row0, aw, base, sel, stepmask, wgt);
-            idx_a = cy.row0;
-        }
-        if (cy.row1 != idx_b) {
-            if (cy.row1 == idx_a) B = A;
-            else B = resize_hrow(fb, cy.row1, aw, base, sel, stepmask, wgt);
-            idx_b = cy.row1;
-        }
+        const uint2 a = s_h[wv][cy.row0 - r_lo][lane], b = s_h[wv][cy.row1 - r_lo][lane];
         const unsigned wy1 = (unsigned)cy.w1, wy0 = 256u - wy1;
+        const unsigned ah[4] = {a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16};
+        const unsigned bh[4] = {b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16};
         unsigned out = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) out |= ((wy0 * A.h[j] + wy1 * B.h[j] + (1u << 15)) >> 16) << (8 * j);
+        for (int j = 0; j < 4; j++) out |= ((wy0 * ah[j] + wy1 * bh[j] + (1u << 15)) >> 16) << (8 * j);
         uint8_t* d = fb + (size_t)(dst.y - border + ty) * aw + ax_begin + dc * 4;
         if (whole) *(unsigned*)d = out;
         else {
