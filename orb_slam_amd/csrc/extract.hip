@@ -343,7 +343,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     }
     T.end(ST_RESIZE, s);
     T.begin(ST_FAST, s);
-    hipLaunchKernelGGL(k_fast_nms<false>, dim3(g.total_tiles, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p,
+    hipLaunchKernelGGL(k_fast_nms<false>, dim3(div_up(g.total_tiles, 8) * 8, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p,
                        h->d_mask.p, A, g, h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255), 0);
     T.end(ST_FAST, s);
     // forked here, not right after the pyramid: FAST fills the chip by itself, emission and selection do not
@@ -626,7 +626,7 @@ orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, ui
         // the detect stage stores scores only where keypoints survive; fill in the whole plane of this frame
         if (!h->pyramid_valid) return ORBX_BAD_ARG;
         ORBX_HIP(hipMemsetAsync(h->d_score.p + (size_t)frame * h->atlas_bytes, 0, h->atlas_bytes, h->stream));
-        hipLaunchKernelGGL(k_fast_nms<true>, dim3(h->geom.total_tiles, 1), dim3(256), 0, h->stream, h->d_atlas.p,
+        hipLaunchKernelGGL(k_fast_nms<true>, dim3(div_up(h->geom.total_tiles, 8) * 8, 1), dim3(256), 0, h->stream, h->d_atlas.p,
                            h->d_score.p, h->d_mask.p, h->atlas_bytes, h->geom, h->d_tiles.p,
                            std::min(std::max(h->prm.score_threshold, 0), 255), frame);
         ORBX_HIP(hipGetLastError());

@@ -285,7 +285,12 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     __shared__ int q_count;
     uint8_t* t = (uint8_t*)t32;
     uint8_t* st = (uint8_t*)s32;
-    const Tile tl = tiles[blockIdx.x];
+    // workgroups go round-robin over the 8 XCDs (each with its own L2): give every XCD one contiguous run of tiles,
+    // so the halo a tile shares with its neighbours is fetched into one L2 only
+    const int per_xcd = (g.total_tiles + 7) >> 3;
+    const int tile_id = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile_id >= g.total_tiles) return;
+    const Tile tl = tiles[tile_id];
     const LevelInfo L = g.L[tl.level];
     const int b = blockIdx.y + frame0;
     const int aw = g.atlas_w;
