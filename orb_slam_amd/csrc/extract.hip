@@ -362,8 +362,12 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
                        h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
-    hipLaunchKernelGGL(k_harris_angle, dim3(frames >= 64 ? 16 : 256, frames), dim3(256), 0, s, h->d_atlas.p, A, g,
-                       h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq);
+    {
+        const int chunks = frames >= 64 ? 16 : 256;
+        hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
+                           h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq,
+                           chunks, frames);
+    }
     T.end(ST_HARRIS, s);
     ORBX_HIP(hipGetLastError());
     h->pyramid_valid = true;
@@ -409,8 +413,12 @@ orbx_status run_describe_stage(orbx_extractor* h, int frames) {
     h->timer.begin(ST_BRIEF, s);
     hipLaunchKernelGGL(k_steer, dim3(div_up(h->kp_cap, 256), frames), dim3(256), 0, s, g, h->d_kp.p, h->d_kp_counts.p,
                        h->kp_cap, h->d_steer.p);
-    hipLaunchKernelGGL(k_brief, dim3(div_up(h->kp_cap, 8), frames), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A,
-                       g.atlas_w, h->d_steer.p, h->d_kp_counts.p, h->kp_cap, h->d_desc.p, h->d_pattern.p);
+    {
+        const int chunks = div_up(h->kp_cap, 8);
+        hipLaunchKernelGGL(k_brief, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, h->d_blur.p, A,
+                           g.atlas_w, h->d_steer.p, h->d_kp_counts.p, h->kp_cap, h->d_desc.p, h->d_pattern.p, chunks,
+                           frames);
+    }
     h->timer.end(ST_BRIEF, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;

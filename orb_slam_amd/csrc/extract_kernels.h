@@ -29,6 +29,16 @@ __device__ __forceinline__ unsigned gray_of(unsigned b, unsigned g, unsigned r) 
     return (b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  For kernels that gather from one frame's
+// planes, a 1-D grid of 8 * chunks * ceil(frames / 8) workgroups decoded here keeps all chunks of a frame on one XCD,
+// so a cache line of the frame is fetched into one L2 only.  Returns false for the padding workgroups.
+__device__ __forceinline__ bool frame_chunk_of_block(int chunks, int frames, int& frame, int& chunk) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    frame = (j / chunks) * 8 + xcd;
+    chunk = j - (j / chunks) * chunks;
+    return frame < frames;
+}
+
 // K1: BGR/gray -> level 0 of the atlas including its reflect-101 border, sixteen atlas pixels per lane (48 source
 // bytes in three 16-byte loads, one 16-byte store).
 // cv::cvtColor(BGR2GRAY) 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14.
@@ -601,9 +611,10 @@ __device__ __forceinline__ int wave_sum_uniform(int v) {
 __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
                                                       Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
                                                       const int* __restrict__ thresholds, UMax umax,
-                                                      float scale_sq_sq) {
+                                                      float scale_sq_sq, int chunks, int frames) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
+    int b, chunk;
+    if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
     const int total = min(totals[b], cap);
     const int aw = g.atlas_w;
     unsigned long long umax4 = 0ull;  // sixteen 4-bit row half-widths
@@ -630,8 +641,8 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
     }
     const int hi = lane / 7 - 3, hj = lane - (lane / 7) * 7 - 3;
     const int h_ofs = lane < 49 ? hi * aw + hj - 1 : -1;
-    // grid-stride over the frame's candidates: gridDim.x * 4 wavefronts per frame
-    for (int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 6); idx < total; idx += gridDim.x * 4) {
+    // the frame's candidates are dealt to chunks * 4 wavefronts
+    for (int idx = chunk * 4 + (int)(threadIdx.x >> 6); idx < total; idx += chunks * 4) {
         Cand* cp = cand + (size_t)b * cap + idx;
         const Cand c = *cp;
         if ((int)c.score < thresholds[b * kMaxLevels + c.level]) continue;
@@ -1021,10 +1032,12 @@ __global__ __launch_bounds__(256) void k_steer(Geom g, const orbx_keypoint* __re
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ blurred,
                                                size_t atlas_bytes, int aw, const Steer* __restrict__ steer,
                                                const int* __restrict__ counts, int kp_cap,
-                                               uint8_t* __restrict__ desc, const BriefPattern* __restrict__ pat) {
-    const int idx = (int)((blockIdx.x * 256u + threadIdx.x) >> 5);
+                                               uint8_t* __restrict__ desc, const BriefPattern* __restrict__ pat,
+                                               int chunks, int frames) {
+    int b, chunk;
+    if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
+    const int idx = (int)((chunk * 256u + threadIdx.x) >> 5);
     const int lane = threadIdx.x & 31;
-    const int b = blockIdx.y;
     if (idx >= counts[b] || idx >= kp_cap) return;
     const uint4* sp = (const uint4*)(steer + (size_t)b * kp_cap + idx);
     const uint4 s0 = sp[0], s1 = sp[1];
