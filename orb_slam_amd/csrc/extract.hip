@@ -65,7 +65,7 @@ struct orbx_extractor {
     DevBuf<MaskWord> d_mask;
     DevBuf<Steer> d_steer;
     DevBuf<Cand> d_cand, d_packed;
-    DevBuf<int> d_level_counts, d_thresholds, d_totals, d_offsets, d_kp_counts;
+    DevBuf<int> d_level_counts, d_thresholds, d_totals, d_offsets, d_kp_counts, d_chunk_counts, d_hist;
     DevBuf<orbx_keypoint> d_kp;
     PinBuf<Cand> h_packed;
     PinBuf<int> h_ints;
@@ -291,6 +291,8 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     ORBX_TRY(h->d_level_counts.ensure((size_t)kMaxLevels * frames));
     ORBX_TRY(h->d_thresholds.ensure((size_t)kMaxLevels * frames));
     ORBX_TRY(h->d_totals.ensure(frames));
+    ORBX_TRY(h->d_chunk_counts.ensure((size_t)kEmitMaxChunks * frames));
+    ORBX_TRY(h->d_hist.ensure((size_t)kMaxLevels * 256 * frames));
     ORBX_TRY(h->d_offsets.ensure(frames + 1));
     ORBX_TRY(h->h_ints.ensure((size_t)frames * (2 * kMaxLevels + 2) + 1));
     return ORBX_OK;
@@ -358,8 +360,18 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
         h->blur_forked = true;
     }
     T.begin(ST_EMIT, s);
-    hipLaunchKernelGGL(k_emit, dim3(frames), dim3(1024), 0, s, h->d_mask.p, h->d_score.p, A, g, h->d_cand.p,
-                       h->cand_cap, h->d_level_counts.p, h->d_thresholds.p, h->d_totals.p);
+    {
+        const int chunks = std::min(std::max(div_up(g.total_words, 4096), 1), kEmitMaxChunks);
+        const int per = div_up(div_up(g.total_words, chunks), 256) * 256;
+        ORBX_HIP(hipMemsetAsync(h->d_hist.p, 0, sizeof(int) * (size_t)kMaxLevels * 256 * frames, s));
+        ORBX_HIP(hipMemsetAsync(h->d_level_counts.p, 0, sizeof(int) * (size_t)kMaxLevels * frames, s));
+        hipLaunchKernelGGL(k_emit_count, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, g, chunks, per,
+                           h->d_chunk_counts.p);
+        hipLaunchKernelGGL(k_emit_write, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, chunks,
+                           per, h->d_chunk_counts.p, h->d_cand.p, h->cand_cap, h->d_level_counts.p, h->d_hist.p);
+        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(64), 0, s, g, chunks, h->d_chunk_counts.p,
+                           h->d_level_counts.p, h->d_hist.p, h->d_thresholds.p, h->d_totals.p);
+    }
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
     {
@@ -578,6 +590,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_coefx.release(); h->d_coefy.release(); h->d_pattern.release();
     h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
     h->d_mask.release(); h->d_steer.release(); h->d_cand.release(); h->d_packed.release();
+    h->d_chunk_counts.release(); h->d_hist.release();
     h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
     h->d_kp_counts.release(); h->d_kp.release();
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();

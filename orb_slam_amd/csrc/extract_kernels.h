@@ -465,28 +465,48 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     return v;
 }
 
-// K4b: ordered emission.  One workgroup per frame; each of its 16 wavefronts owns a contiguous run of mask words
-// (level-major raster order), counts its set bits, and after one exchange of the 16 totals appends its corners at
-// their exact rank, so the candidate list has the order cv::FAST emits.  Also builds the per-level histogram of
-// FAST scores and from it the score of the (2*quota)-th best corner: the value
-// KeyPointsFilter::retainBest(2*quota) keeps everything at or above.
-__global__ __launch_bounds__(1024) void k_emit(const MaskWord* __restrict__ mask,
-                                               const uint8_t* __restrict__ score, size_t atlas_bytes, Geom g,
-                                               Cand* __restrict__ cand, int cap, int* __restrict__ level_counts,
-                                               int* __restrict__ thresholds, int* __restrict__ totals) {
+// K4b: ordered emission, in three small kernels so that a frame is not tied to one workgroup.  The mask words of a
+// frame (level-major raster order) are cut into `chunks` equal runs:
+//   k_emit_count   set bits per run;
+//   k_emit_write   a workgroup per run: its base rank is the sum of the earlier runs' counts, its four wavefronts own
+//                  a quarter of the run each and append their corners at their exact rank, so the candidate list has
+//                  the order cv::FAST emits; per-level counts and score histograms are accumulated on the side;
+//   k_emit_finish  totals, and from the histograms the score of the (2*quota)-th best corner of every level: the
+//                  value KeyPointsFilter::retainBest(2*quota) keeps everything at or above.
+constexpr int kEmitMaxChunks = 64;
+
+__global__ __launch_bounds__(256) void k_emit_count(const MaskWord* __restrict__ mask, Geom g, int chunks, int per,
+                                                    int* __restrict__ chunk_counts) {
+    __shared__ int s_w[4];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const MaskWord* mk = mask + (size_t)b * g.total_words;
+    const int w0 = min(c * per, g.total_words), w1 = min(w0 + per, g.total_words);
+    int mine = 0;
+    for (int word = w0 + threadIdx.x; word < w1; word += 256) mine += __popcll(mk[word].bits);
+    mine = wave_scan_incl(mine);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_counts[b * kEmitMaxChunks + c] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void k_emit_write(const MaskWord* __restrict__ mask, const uint8_t* __restrict__ score,
+                                                    size_t atlas_bytes, Geom g, int chunks, int per,
+                                                    const int* __restrict__ chunk_counts, Cand* __restrict__ cand,
+                                                    int cap, int* __restrict__ level_counts, int* __restrict__ hist_g) {
     __shared__ int hist[kMaxLevels][256];
     __shared__ int lcount[kMaxLevels];
-    __shared__ int wave_tot[16];
-    const int b = blockIdx.x;
+    __shared__ int wave_tot[4];
+    const int b = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < kMaxLevels * 256; i += 1024) (&hist[0][0])[i] = 0;
+    for (int i = tid; i < kMaxLevels * 256; i += 256) (&hist[0][0])[i] = 0;
     if (tid < kMaxLevels) lcount[tid] = 0;
     const MaskWord* mk = mask + (size_t)b * g.total_words;
     const uint8_t* sc = score + (size_t)b * atlas_bytes;
     Cand* out = cand + (size_t)b * cap;
     const int lane = tid & 63, wv = tid >> 6;
-    const int per = ((g.total_words + 15) / 16 + 63) / 64 * 64;
-    const int w0 = min(wv * per, g.total_words), w1 = min(w0 + per, g.total_words);
+    const int c0 = min(c * per, g.total_words);
+    const int quarter = per >> 2;  // per is a multiple of 256
+    const int w0 = min(c0 + wv * quarter, g.total_words), w1 = min(min(w0 + quarter, c0 + per), g.total_words);
     int mine = 0;
     for (int base = w0; base < w1; base += 64) {
         const int word = base + lane;
@@ -494,20 +514,19 @@ __global__ __launch_bounds__(1024) void k_emit(const MaskWord* __restrict__ mask
     }
     mine = wave_scan_incl(mine);
     if (lane == 63) wave_tot[wv] = mine;
+    int before = 0;  // corners of the earlier runs of this frame
+    for (int k = lane; k < c; k += 64) before += chunk_counts[b * kEmitMaxChunks + k];
+    before = __builtin_amdgcn_readlane(wave_scan_incl(before), 63);
     __syncthreads();
-    int running = 0, all = 0;
-    for (int k = 0; k < 16; k++) {
-        const int t = wave_tot[k];
-        if (k < wv) running += t;
-        all += t;
-    }
+    int running = before;
+    for (int k = 0; k < wv; k++) running += wave_tot[k];
     for (int base = w0; base < w1; base += 64) {
         const int word = base + lane;
         const MaskWord mw = word < w1 ? mk[word] : MaskWord{0ull, 0ull};
         unsigned long long m = mw.bits;
-        const int c = __popcll(m);
-        const int incl = wave_scan_incl(c);
-        int pos = running + incl - c;
+        const int cnt = __popcll(m);
+        const int incl = wave_scan_incl(cnt);
+        int pos = running + incl - cnt;
         running += __builtin_amdgcn_readlane(incl, 63);
         if (m) {
             int l = 0;
@@ -516,7 +535,7 @@ __global__ __launch_bounds__(1024) void k_emit(const MaskWord* __restrict__ mask
             const int r = word - L.word_base;
             const int y = r / L.words_per_row;
             const int x0 = (r - y * L.words_per_row) * 64;
-            atomicAdd(&lcount[l], c);
+            atomicAdd(&lcount[l], cnt);
             int rank = 0;
             while (m) {
                 const int bit = __ffsll((long long)m) - 1;
@@ -542,8 +561,22 @@ __global__ __launch_bounds__(1024) void k_emit(const MaskWord* __restrict__ mask
         }
     }
     __syncthreads();
+    int* hg = hist_g + (size_t)b * kMaxLevels * 256;
+    for (int i = tid; i < g.nlevels * 256; i += 256) {
+        const int v = (&hist[0][0])[i];
+        if (v) atomicAdd(&hg[i], v);
+    }
+    if (tid < g.nlevels && lcount[tid]) atomicAdd(&level_counts[b * kMaxLevels + tid], lcount[tid]);
+}
+
+__global__ __launch_bounds__(64) void k_emit_finish(Geom g, int chunks, const int* __restrict__ chunk_counts,
+                                                    const int* __restrict__ level_counts,
+                                                    const int* __restrict__ hist_g, int* __restrict__ thresholds,
+                                                    int* __restrict__ totals) {
+    const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < g.nlevels) {
-        const int n = lcount[tid];
+        const int* hl = hist_g + ((size_t)b * kMaxLevels + tid) * 256;
+        const int n = level_counts[b * kMaxLevels + tid];
         const int want = 2 * g.L[tid].quota;
         int t = 0;
         if (n > want) {
@@ -551,15 +584,16 @@ __global__ __launch_bounds__(1024) void k_emit(const MaskWord* __restrict__ mask
             else {
                 int acc = 0;
                 for (int s = 255; s >= 0; s--) {
-                    acc += hist[tid][s];
+                    acc += hl[s];
                     if (acc >= want) { t = s; break; }
                 }
             }
         }
-        level_counts[b * kMaxLevels + tid] = n;
         thresholds[b * kMaxLevels + tid] = t;
     }
-    if (tid == 0) totals[b] = all;
+    int all = tid < chunks ? chunk_counts[b * kEmitMaxChunks + tid] : 0;
+    all = wave_scan_incl(all);
+    if (tid == 63) totals[b] = all;
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
