@@ -7,7 +7,7 @@ namespace orbx {
 
 constexpr int kMaxLevels = 16;
 constexpr int kTileW = 64;   // FAST tile: 64 x 32 level pixels per 256-thread workgroup
-constexpr int kTileH = 32;
+constexpr int kTileH = 64;
 
 struct LevelInfo {
     int x, y, w, h;        // un-padded level rectangle inside the atlas
