@@ -675,46 +675,73 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
     }
     const int hi = lane / 7 - 3, hj = lane - (lane / 7) * 7 - 3;
     const int h_ofs = lane < 49 ? hi * aw + hj - 1 : -1;
-    // the frame's candidates are dealt to chunks * 4 wavefronts
-    for (int idx = chunk * 4 + (int)(threadIdx.x >> 6); idx < total; idx += chunks * 4) {
-        Cand* cp = cand + (size_t)b * cap + idx;
-        const Cand c = *cp;
-        if ((int)c.score < thresholds[b * kMaxLevels + c.level]) continue;
-        const LevelInfo L = g.L[c.level];
-        const uint8_t* center = atlas + (size_t)b * atlas_bytes + (size_t)(L.y + c.y) * aw + L.x + c.x;
-        const uint8_t* hp = center + h_ofs;
-        const unsigned r0 = load_u32_any(hp - aw), r1 = load_u32_any(hp), r2 = load_u32_any(hp + aw);
-        const uint8_t* ip = center + row_ofs;
-        unsigned q[4];
+    // The frame's candidates are dealt to chunks * 4 wavefronts.  A wavefront's work per candidate is a chain of
+    // dependent loads (candidate -> pixels), so it runs as a software pipeline: the candidate record two steps
+    // ahead and the pixels one step ahead are in flight while the current candidate is reduced.
+    const int stride = chunks * 4;
+    const int idx0 = chunk * 4 + (int)(threadIdx.x >> 6);
+    const int thr_l = lane < kMaxLevels ? thresholds[b * kMaxLevels + lane] : 0;
+    Cand* cbase = cand + (size_t)b * cap;
+    const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
+    struct Px { unsigned r0, r1, r2; uint4 q; bool live; };
+    auto fetch_px = [&](const Cand& c, bool valid) {
+        Px p;
+        p.r0 = p.r1 = p.r2 = 0u;
+        p.q = make_uint4(0u, 0u, 0u, 0u);
+        const int lvl = __builtin_amdgcn_readfirstlane((int)c.level) & (kMaxLevels - 1);
+        p.live = valid && (int)c.score >= __builtin_amdgcn_readlane(thr_l, lvl);
+        if (p.live) {
+            const LevelInfo L = g.L[lvl];
+            const uint8_t* center = fb + (size_t)(L.y + c.y) * aw + L.x + c.x;
+            const uint8_t* hp = center + h_ofs;
+            p.r0 = load_u32_any(hp - aw);
+            p.r1 = load_u32_any(hp);
+            p.r2 = load_u32_any(hp + aw);
+            p.q = load_u128_any(center + row_ofs);
+        }
+        return p;
+    };
+    Cand c_cur = cbase[min(idx0, max(total - 1, 0))];
+    Cand c_nxt = cbase[min(idx0 + stride, max(total - 1, 0))];
+    Px px_cur = fetch_px(c_cur, idx0 < total);
+    for (int idx = idx0; idx < total; idx += stride) {
+        const Cand c_nn = cbase[min(idx + 2 * stride, total - 1)];
+        const Px px_nxt = fetch_px(c_nxt, idx + stride < total);
+        if (px_cur.live) {
+            const unsigned r0 = px_cur.r0, r1 = px_cur.r1, r2 = px_cur.r2;
+            const unsigned q[4] = {px_cur.q.x, px_cur.q.y, px_cur.q.z, px_cur.q.w};
+            int ha = 0, hb = 0, hc = 0;
+            if (lane < 49) {
+                const int a0 = r0 & 255, a1 = (r0 >> 8) & 255, a2 = (r0 >> 16) & 255;
+                const int b0 = r1 & 255, b2 = (r1 >> 16) & 255;
+                const int c0 = r2 & 255, c1 = (r2 >> 8) & 255, c2 = (r2 >> 16) & 255;
+                const int Ix = (b2 - b0) * 2 + (a2 - a0) + (c2 - c0);
+                const int Iy = (c1 - a1) * 2 + (c0 - a0) + (c2 - a2);
+                ha = Ix * Ix;
+                hb = Iy * Iy;
+                hc = Ix * Iy;
+            }
+            unsigned ssum = 0, wsum = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = load_u32_any(ip + 4 * j);
-        int ha = 0, hb = 0, hc = 0;
-        if (lane < 49) {
-            const int a0 = r0 & 255, a1 = (r0 >> 8) & 255, a2 = (r0 >> 16) & 255;
-            const int b0 = r1 & 255, b2 = (r1 >> 16) & 255;
-            const int c0 = r2 & 255, c1 = (r2 >> 8) & 255, c2 = (r2 >> 16) & 255;
-            const int Ix = (b2 - b0) * 2 + (a2 - a0) + (c2 - c0);
-            const int Iy = (c1 - a1) * 2 + (c0 - a0) + (c2 - a2);
-            ha = Ix * Ix;
-            hb = Iy * Iy;
-            hc = Ix * Iy;
+            for (int j = 0; j < 4; j++) {
+                const unsigned m = q[j] & msk[j];
+                ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
+                wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
+            }
+            const int sha = wave_sum_uniform(ha), shb = wave_sum_uniform(hb), shc = wave_sum_uniform(hc);
+            const int m10 = wave_sum_uniform(right ? (int)wsum : -(int)wsum);
+            const int m01 = wave_sum_uniform(v * (int)ssum);
+            if (lane == 0) {
+                const float fa = (float)sha, fb2 = (float)shb, fc = (float)shc;
+                const float resp = (fa * fb2 - fc * fc - 0.04f * (fa + fb2) * (fa + fb2)) * scale_sq_sq;
+                Cand* cp = cbase + idx;
+                cp->harris = resp;
+                cp->angle = fast_atan2_deg((float)m01, (float)m10);
+            }
         }
-        unsigned ssum = 0, wsum = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned m = q[j] & msk[j];
-            ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
-            wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
-        }
-        const int sha = wave_sum_uniform(ha), shb = wave_sum_uniform(hb), shc = wave_sum_uniform(hc);
-        const int m10 = wave_sum_uniform(right ? (int)wsum : -(int)wsum);
-        const int m01 = wave_sum_uniform(v * (int)ssum);
-        if (lane == 0) {
-            const float fa = (float)sha, fb = (float)shb, fc = (float)shc;
-            const float resp = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
-            cp->harris = resp;
-            cp->angle = fast_atan2_deg((float)m01, (float)m10);
-        }
+        c_cur = c_nxt;
+        c_nxt = c_nn;
+        px_cur = px_nxt;
     }
 }
 
