@@ -1090,14 +1090,24 @@ __global__ __launch_bounds__(256) void k_steer(Geom g, const orbx_keypoint* __re
 // K8: rotated BRIEF (cv::ORB computeOrbDescriptors, WTA_K = 2).  32 lanes per keypoint, one descriptor byte per
 // lane.  Samples inside the level come from the blurred plane; samples in the level's border come from the
 // un-blurred atlas, which is what cv::ORB reads there (it blurs level interiors in place).
+// The pattern's points lie within 18.4 pixels of the centre, so the rotated, rounded samples stay within +-18: when
+// that square is inside the level (always, for keypoints cv::ORB::detect returns with the default edge threshold)
+// the 39 x 39 patch is staged in LDS with 4-byte row loads and the 512 samples are LDS reads; otherwise every
+// sample is fetched from memory.
+constexpr int kBriefR = 19;                      // staged patch radius
+constexpr int kBriefPitch = 40;                  // bytes per staged row (10 dwords)
+constexpr int kBriefRows = 2 * kBriefR + 1;
+
 __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ blurred,
                                                size_t atlas_bytes, int aw, const Steer* __restrict__ steer,
                                                const int* __restrict__ counts, int kp_cap,
                                                uint8_t* __restrict__ desc, const BriefPattern* __restrict__ pat,
                                                int chunks, int frames) {
+    __shared__ unsigned s_patch[8][kBriefRows * kBriefPitch / 4];
     int b, chunk;
     if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
-    const int idx = (int)((chunk * 256u + threadIdx.x) >> 5);
+    const int slot = threadIdx.x >> 5;
+    const int idx = chunk * 8 + slot;
     const int lane = threadIdx.x & 31;
     if (idx >= counts[b] || idx >= kp_cap) return;
     const uint4* sp = (const uint4*)(steer + (size_t)b * kp_cap + idx);
@@ -1105,7 +1115,29 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
     const float a = __uint_as_float(s0.x), bb = __uint_as_float(s0.y);
     const int cx = (int)s0.z, cy = (int)s0.w, lw = (int)s1.y, lh = (int)s1.z;
     const size_t org = (size_t)b * atlas_bytes + (size_t)(int)s1.x;
-    const int* q = (const int*)(pat->p + lane * 32);  // four signed bytes per test: x0, y0, x1, y1
+    // four signed bytes per test (x0, y0, x1, y1), this lane's eight tests in two 16-byte loads
+    const uint4* qp = (const uint4*)(pat->p + lane * 32);
+    const uint4 qa = qp[0], qb = qp[1];
+    const int q[8] = {(int)qa.x, (int)qa.y, (int)qa.z, (int)qa.w, (int)qb.x, (int)qb.y, (int)qb.z, (int)qb.w};
+    const bool staged = cx - kBriefR >= 0 && cx + kBriefR + 1 < lw && cy - kBriefR >= 0 && cy + kBriefR < lh;
+    if (staged) {
+        const uint8_t* corner = blurred + org + (ptrdiff_t)(cy - kBriefR) * aw + (cx - kBriefR);
+        constexpr int kDwords = kBriefRows * (kBriefPitch / 4), kSteps = (kDwords + 31) / 32;
+        unsigned tmp[kSteps];
+#pragma unroll
+        for (int k = 0; k < kSteps; k++) {  // all row loads in flight, then the LDS stores
+            const int i = min(lane + 32 * k, kDwords - 1);
+            const int r = i / (kBriefPitch / 4), c = i - r * (kBriefPitch / 4);
+            tmp[k] = load_u32_any(corner + (ptrdiff_t)r * aw + 4 * c);
+        }
+#pragma unroll
+        for (int k = 0; k < kSteps; k++)
+            if (lane + 32 * k < kDwords) s_patch[slot][lane + 32 * k] = tmp[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t* sp8 = (const uint8_t*)s_patch[slot] + kBriefR * kBriefPitch + kBriefR;  // the centre pixel
     int val = 0;
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
@@ -1114,14 +1146,21 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
         const float px1 = (float)(int)(signed char)((pq >> 16) & 0xff), py1 = (float)(int)(signed char)(pq >> 24);
         const float x0 = px0 * a - py0 * bb, y0 = px0 * bb + py0 * a;
         const float x1 = px1 * a - py1 * bb, y1 = px1 * bb + py1 * a;
-        const int sx0 = cx + __float2int_rn(x0), sy0 = cy + __float2int_rn(y0);
-        const int sx1 = cx + __float2int_rn(x1), sy1 = cy + __float2int_rn(y1);
-        const bool in0 = (unsigned)sx0 < (unsigned)lw && (unsigned)sy0 < (unsigned)lh;
-        const bool in1 = (unsigned)sx1 < (unsigned)lw && (unsigned)sy1 < (unsigned)lh;
-        const uint8_t* src0 = in0 ? blurred : atlas;
-        const uint8_t* src1 = in1 ? blurred : atlas;
-        const int t0 = src0[org + (ptrdiff_t)sy0 * aw + sx0];
-        const int t1 = src1[org + (ptrdiff_t)sy1 * aw + sx1];
+        const int dx0 = __float2int_rn(x0), dy0 = __float2int_rn(y0);
+        const int dx1 = __float2int_rn(x1), dy1 = __float2int_rn(y1);
+        int t0, t1;
+        if (staged) {
+            t0 = sp8[dy0 * kBriefPitch + dx0];
+            t1 = sp8[dy1 * kBriefPitch + dx1];
+        } else {
+            const int sx0 = cx + dx0, sy0 = cy + dy0, sx1 = cx + dx1, sy1 = cy + dy1;
+            const bool in0 = (unsigned)sx0 < (unsigned)lw && (unsigned)sy0 < (unsigned)lh;
+            const bool in1 = (unsigned)sx1 < (unsigned)lw && (unsigned)sy1 < (unsigned)lh;
+            const uint8_t* src0 = in0 ? blurred : atlas;
+            const uint8_t* src1 = in1 ? blurred : atlas;
+            t0 = src0[org + (ptrdiff_t)sy0 * aw + sx0];
+            t1 = src1[org + (ptrdiff_t)sy1 * aw + sx1];
+        }
         val |= (int)(t0 < t1) << bit;
     }
     desc[((size_t)b * kp_cap + idx) * 32 + lane] = (uint8_t)val;
