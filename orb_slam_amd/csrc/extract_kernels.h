@@ -322,10 +322,19 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     const int ox = L.x + tl.x0 - 4, oy = L.y + tl.y0 - 4;
     const int abase = ox & ~3, off = ox & 3;
     const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
-    for (int i = tid; i < kFRows * (kFPitch / 4); i += 256) {
-        const int r = i / (kFPitch / 4), c = i - r * (kFPitch / 4);
-        const int ax = min(abase + 4 * c, aw - 4), ay = min(oy + r, g.atlas_h - 1);
-        t32[i] = *(const unsigned*)(fb + (size_t)ay * aw + ax);
+    {
+        constexpr int kDwords = kFRows * (kFPitch / 4), kSteps = (kDwords + 255) / 256;
+        unsigned tmp[kSteps];
+#pragma unroll
+        for (int k = 0; k < kSteps; k++) {  // all loads in flight, then the LDS stores
+            const int i = min(tid + 256 * k, kDwords - 1);
+            const int r = i / (kFPitch / 4), c = i - r * (kFPitch / 4);
+            const int ax = min(abase + 4 * c, aw - 4), ay = min(oy + r, g.atlas_h - 1);
+            tmp[k] = *(const unsigned*)(fb + (size_t)ay * aw + ax);
+        }
+#pragma unroll
+        for (int k = 0; k < kSteps; k++)
+            if (tid + 256 * k < kDwords) t32[tid + 256 * k] = tmp[k];
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
     if (tid < 2 * kTileH) {
