@@ -747,7 +747,9 @@ struct ItemRec {
     float x, y;
     uint32_t idx_oct;   // feature index | (octave saturated to int8) << 24
     uint16_t cx, cy;    // grid cell
+    uint32_t desc[8];   // the feature's descriptor: one record fetch gives the test inputs and the distance inputs
 };
+static_assert(sizeof(ItemRec) == 48, "ItemRec is read as three 16-byte words");
 
 // K10r: CSR-ordered feature records of the frame of every pair (one thread per grid cell).
 __global__ __launch_bounds__(256) void k_item_records(ProjArgs A, ItemRec* __restrict__ recs) {
@@ -759,18 +761,20 @@ __global__ __launch_bounds__(256) void k_item_records(ProjArgs A, ItemRec* __res
     const int32_t* cs = A.cell_start + (size_t)fi * A.cell_stride;
     const int32_t* ci = A.cell_items + (size_t)fi * A.kp_stride;
     const orbx_keypoint* kps = A.kps + (size_t)fi * A.kp_stride;
+    const uint8_t* desc = A.desc + (size_t)fi * A.kp_stride * 32;
     ItemRec* out = recs + (size_t)pair * A.kp_stride;
     const int i0 = cs[cell], i1 = cs[cell + 1];
     for (int i = i0; i < i1; i++) {
         const int idx = ci[i];
         const orbx_keypoint k = kps[idx];
-        ItemRec r;
-        r.x = k.x;
-        r.y = k.y;
-        r.idx_oct = (uint32_t)idx | ((uint32_t)(min(max(k.octave, -128), 127) & 0xff) << 24);
-        r.cx = (uint16_t)(cell / A.g.grid_rows);
-        r.cy = (uint16_t)(cell % A.g.grid_rows);
-        out[i] = r;
+        const uint4* dp = (const uint4*)(desc + (size_t)idx * 32);
+        const uint4 d0 = dp[0], d1 = dp[1];
+        uint4* o = (uint4*)(out + i);
+        o[0] = make_uint4(__float_as_uint(k.x), __float_as_uint(k.y),
+                          (uint32_t)idx | ((uint32_t)(min(max(k.octave, -128), 127) & 0xff) << 24),
+                          (uint32_t)(cell / A.g.grid_rows) | ((uint32_t)(cell % A.g.grid_rows) << 16));
+        o[1] = d0;
+        o[2] = d1;
     }
 }
 
@@ -810,9 +814,14 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
     __shared__ int2 s_ent[16][kSortK];
     __shared__ int s_incl[16][16];
     __shared__ int s_first[16][16];
+    __shared__ float s_sf[64];
     const int gl = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
     const int sub = (threadIdx.x >> 4) & 3;  // group inside the wavefront
+    // the per-level radius factors sit in LDS: one dependent memory round trip less per reference point
+    if ((int)threadIdx.x < min(A.n_levels, 64)) s_sf[threadIdx.x] = A.scale_factors[threadIdx.x];
+    __syncthreads();
+    A.scale_factors = s_sf;
     const ItemRec* recs = recs_all + (size_t)blockIdx.y * A.kp_stride;
     resolve_views(A, blockIdx.y);
     const int ref_idx = blockIdx.x * 16 + grp;
@@ -839,27 +848,43 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
         s_incl[grp][gl] = incl;
         s_first[grp][gl] = start - (incl - len);  // record of item t of this run = first + t
         wave_lds_fence();
-        for (int tb = 0; tb < total && list_n <= kSortK; tb += 16) {
-            const int t = tb + gl;
-            bool ok = false;
-            ItemRec r;
-            if (t < total) {
-                int run = 0;
-                while (t >= s_incl[grp][run]) run++;
-                r = recs[s_first[grp][run] + t];
-                ok = in_window_rec(r, W);
+        // two records per lane and step: both fetches are in flight together
+        for (int tb = 0; tb < total && list_n <= kSortK; tb += 32) {
+            uint4 w0[2], w1[2], w2[2];
+            bool in[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int t = tb + 16 * u + gl;
+                in[u] = t < total;
+                w0[u] = w1[u] = w2[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (in[u]) {
+                    int run = 0;
+                    while (t >= s_incl[grp][run]) run++;
+                    const uint4* rp = (const uint4*)(recs + s_first[grp][run] + t);
+                    w0[u] = rp[0];
+                    w1[u] = rp[1];
+                    w2[u] = rp[2];
+                }
             }
-            const unsigned gm = (unsigned)(__ballot(ok) >> (16 * sub)) & 0xffffu;
-            const int pos = list_n + __popc(gm & ((1u << gl) - 1u));
-            if (ok && pos < kSortK) {
-                const int idx = (int)(r.idx_oct & 0xffffffu);
-                const uint4* dp = (const uint4*)(A.desc + (size_t)idx * 32);
-                const uint4 da = dp[0], db = dp[1];
-                const int d = __popc(ra.x ^ da.x) + __popc(ra.y ^ da.y) + __popc(ra.z ^ da.z) + __popc(ra.w ^ da.w) +
-                              __popc(rb.x ^ db.x) + __popc(rb.y ^ db.y) + __popc(rb.z ^ db.z) + __popc(rb.w ^ db.w);
-                s_ent[grp][pos] = make_int2(idx, d);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                ItemRec r;
+                r.x = __uint_as_float(w0[u].x);
+                r.y = __uint_as_float(w0[u].y);
+                r.idx_oct = w0[u].z;
+                r.cx = (uint16_t)(w0[u].w & 0xffffu);
+                r.cy = (uint16_t)(w0[u].w >> 16);
+                const bool ok = in[u] && in_window_rec(r, W);
+                const unsigned gm = (unsigned)(__ballot(ok) >> (16 * sub)) & 0xffffu;
+                const int pos = list_n + __popc(gm & ((1u << gl) - 1u));
+                if (ok && pos < kSortK) {
+                    const int d = __popc(ra.x ^ w1[u].x) + __popc(ra.y ^ w1[u].y) + __popc(ra.z ^ w1[u].z) +
+                                  __popc(ra.w ^ w1[u].w) + __popc(rb.x ^ w2[u].x) + __popc(rb.y ^ w2[u].y) +
+                                  __popc(rb.z ^ w2[u].z) + __popc(rb.w ^ w2[u].w);
+                    s_ent[grp][pos] = make_int2((int)(r.idx_oct & 0xffffffu), d);
+                }
+                list_n += __popc(gm);
             }
-            list_n += __popc(gm);
         }
         wave_lds_fence();
     }
@@ -1415,7 +1440,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
         ORBX_HIP(hipGetLastError());
         return ORBX_OK;
     }
-    ORBX_TRY(h->d_recs.ensure((size_t)kp_capacity * n_pairs * sizeof(ItemRec)));
+    ORBX_TRY(h->d_recs.ensure((size_t)kp_capacity * n_pairs * sizeof(ItemRec) + 64));
     ItemRec* recs = (ItemRec*)h->d_recs.p;
     const int ncells = g->grid_cols * g->grid_rows;
     if (g->grid_cols > 65535 || g->grid_rows > 65535 || kp_capacity >= (1 << 24)) return ORBX_UNSUPPORTED;
