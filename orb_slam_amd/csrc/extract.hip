@@ -65,7 +65,15 @@ struct orbx_extractor {
     DevBuf<MaskWord> d_mask;
     DevBuf<Steer> d_steer;
     DevBuf<Cand> d_cand, d_packed;
-    DevBuf<int> d_level_counts, d_thresholds, d_totals, d_offsets, d_kp_counts, d_chunk_counts, d_hist;
+    DevBuf<int> d_thresholds, d_totals, d_offsets, d_kp_counts;
+    // accumulators zeroed once per batch, back to back in one allocation: per-level counts [frames][kMaxLevels],
+    // per-run corner counts [frames][kEmitMaxChunks], per-level score histograms [frames][kMaxLevels][256]
+    DevBuf<int> d_acc;
+    int* d_level_counts_p = nullptr;
+    int* d_chunk_counts_p = nullptr;
+    int* d_hist_p = nullptr;
+    size_t acc_ints = 0;
+    int emit_chunks = 1, emit_per = 256;
     DevBuf<orbx_keypoint> d_kp;
     PinBuf<Cand> h_packed;
     PinBuf<int> h_ints;
@@ -288,11 +296,15 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     if (cap > h->cand_cap) h->cand_cap = cap;
     ORBX_TRY(h->d_cand.ensure((size_t)h->cand_cap * frames));
     ORBX_TRY(h->d_packed.ensure((size_t)h->cand_cap * frames));
-    ORBX_TRY(h->d_level_counts.ensure((size_t)kMaxLevels * frames));
+    h->acc_ints = (size_t)frames * (kMaxLevels + kEmitMaxChunks + kMaxLevels * 256);
+    ORBX_TRY(h->d_acc.ensure(h->acc_ints));
+    h->d_level_counts_p = h->d_acc.p;
+    h->d_chunk_counts_p = h->d_level_counts_p + (size_t)frames * kMaxLevels;
+    h->d_hist_p = h->d_chunk_counts_p + (size_t)frames * kEmitMaxChunks;
+    h->emit_chunks = std::min(std::max(div_up(g.total_words, 4096), 1), kEmitMaxChunks);
+    h->emit_per = div_up(div_up(g.total_words, h->emit_chunks), 256) * 256;
     ORBX_TRY(h->d_thresholds.ensure((size_t)kMaxLevels * frames));
     ORBX_TRY(h->d_totals.ensure(frames));
-    ORBX_TRY(h->d_chunk_counts.ensure((size_t)kEmitMaxChunks * frames));
-    ORBX_TRY(h->d_hist.ensure((size_t)kMaxLevels * 256 * frames));
     ORBX_TRY(h->d_offsets.ensure(frames + 1));
     ORBX_TRY(h->h_ints.ensure((size_t)frames * (2 * kMaxLevels + 2) + 1));
     return ORBX_OK;
@@ -345,8 +357,10 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     }
     T.end(ST_RESIZE, s);
     T.begin(ST_FAST, s);
+    ORBX_HIP(hipMemsetAsync(h->d_acc.p, 0, sizeof(int) * h->acc_ints, s));
     hipLaunchKernelGGL(k_fast_nms<false>, dim3(div_up(g.total_tiles, 8) * 8, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p,
-                       h->d_mask.p, A, g, h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255), 0);
+                       h->d_mask.p, A, g, h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255), 0,
+                       h->d_chunk_counts_p, h->emit_per);
     T.end(ST_FAST, s);
     // forked here, not right after the pyramid: FAST fills the chip by itself, emission and selection do not
     if (fork_blur) {
@@ -361,16 +375,11 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     }
     T.begin(ST_EMIT, s);
     {
-        const int chunks = std::min(std::max(div_up(g.total_words, 4096), 1), kEmitMaxChunks);
-        const int per = div_up(div_up(g.total_words, chunks), 256) * 256;
-        ORBX_HIP(hipMemsetAsync(h->d_hist.p, 0, sizeof(int) * (size_t)kMaxLevels * 256 * frames, s));
-        ORBX_HIP(hipMemsetAsync(h->d_level_counts.p, 0, sizeof(int) * (size_t)kMaxLevels * frames, s));
-        hipLaunchKernelGGL(k_emit_count, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, g, chunks, per,
-                           h->d_chunk_counts.p);
+        const int chunks = h->emit_chunks, per = h->emit_per;
         hipLaunchKernelGGL(k_emit_write, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, chunks,
-                           per, h->d_chunk_counts.p, h->d_cand.p, h->cand_cap, h->d_level_counts.p, h->d_hist.p);
-        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(64), 0, s, g, chunks, h->d_chunk_counts.p,
-                           h->d_level_counts.p, h->d_hist.p, h->d_thresholds.p, h->d_totals.p);
+                           per, h->d_chunk_counts_p, h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_hist_p);
+        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(64), 0, s, g, chunks, h->d_chunk_counts_p,
+                           h->d_level_counts_p, h->d_hist_p, h->d_thresholds.p, h->d_totals.p);
     }
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
@@ -454,7 +463,7 @@ orbx_status select_keypoints(orbx_extractor* h, int frames, std::vector<std::vec
     int* h_counts = hi + 2 * frames + 1;
     ORBX_HIP(hipMemcpyAsync(h_totals, h->d_totals.p, sizeof(int) * frames, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipMemcpyAsync(h_offsets, h->d_offsets.p, sizeof(int) * (frames + 1), hipMemcpyDeviceToHost, s));
-    ORBX_HIP(hipMemcpyAsync(h_counts, h->d_level_counts.p, sizeof(int) * kMaxLevels * frames, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(h_counts, h->d_level_counts_p, sizeof(int) * kMaxLevels * frames, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipStreamSynchronize(s));
     for (int f = 0; f < frames; f++)
         if (h_totals[f] > h->cand_cap) return ORBX_CAPACITY;
@@ -590,8 +599,8 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_coefx.release(); h->d_coefy.release(); h->d_pattern.release();
     h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
     h->d_mask.release(); h->d_steer.release(); h->d_cand.release(); h->d_packed.release();
-    h->d_chunk_counts.release(); h->d_hist.release();
-    h->d_level_counts.release(); h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
+    h->d_acc.release();
+    h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
     h->d_kp_counts.release(); h->d_kp.release();
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();
     h->d_cell_start.release(); h->d_cell_items.release(); h->h_cell_start.release(); h->h_cell_items.release();
@@ -649,7 +658,7 @@ orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, ui
         ORBX_HIP(hipMemsetAsync(h->d_score.p + (size_t)frame * h->atlas_bytes, 0, h->atlas_bytes, h->stream));
         hipLaunchKernelGGL(k_fast_nms<true>, dim3(div_up(h->geom.total_tiles, 8) * 8, 1), dim3(256), 0, h->stream, h->d_atlas.p,
                            h->d_score.p, h->d_mask.p, h->atlas_bytes, h->geom, h->d_tiles.p,
-                           std::min(std::max(h->prm.score_threshold, 0), 255), frame);
+                           std::min(std::max(h->prm.score_threshold, 0), 255), frame, nullptr, 1);
         ORBX_HIP(hipGetLastError());
     }
     ORBX_HIP(hipStreamSynchronize(h->stream));
@@ -800,7 +809,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         }
         h->timer.begin(ST_SELECT, h->stream);
         hipLaunchKernelGGL(k_select_frame, dim3(n_frames), dim3(64 * h->geom.nlevels), shmem, h->stream, h->d_cand.p,
-                           h->cand_cap, h->d_level_counts.p, h->d_totals.p, h->geom, fm, h->d_kp.p, capacity,
+                           h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm, h->d_kp.p, capacity,
                            h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p);
         h->timer.end(ST_SELECT, h->stream);
         ORBX_HIP(hipGetLastError());

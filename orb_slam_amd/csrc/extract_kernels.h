@@ -286,7 +286,8 @@ constexpr int kFGroups = 18;             // staged dwords per row that can hold 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
                                                   MaskWord* __restrict__ mask, size_t atlas_bytes, Geom g,
-                                                  const Tile* __restrict__ tiles, int threshold, int frame0) {
+                                                  const Tile* __restrict__ tiles, int threshold, int frame0,
+                                                  int* __restrict__ chunk_counts, int words_per_chunk) {
     __shared__ unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
     __shared__ unsigned short queue[kSW * kSH];
@@ -449,11 +450,31 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         else if (!DENSE) sc[(size_t)r * aw + cc] = (uint8_t)c;
     }
     __syncthreads();
-    if (tid < kTileH && tl.y0 + tid < L.h) {
-        MaskWord w;
-        w.bits = (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
-        w.scores = (unsigned long long)s_sc8[2 * tid] | ((unsigned long long)s_sc8[2 * tid + 1] << 32);
-        mk[(size_t)(tl.y0 + tid) * L.words_per_row] = w;
+    if (tid < 64) {  // kTileH <= 64: one wavefront writes the tile's rows and totals their keypoints per emission run
+        const bool row = tid < kTileH && tl.y0 + tid < L.h;
+        int cnt = 0, run = -1;
+        if (row) {
+            MaskWord w;
+            w.bits = (unsigned long long)s_mask[2 * tid] | ((unsigned long long)s_mask[2 * tid + 1] << 32);
+            w.scores = (unsigned long long)s_sc8[2 * tid] | ((unsigned long long)s_sc8[2 * tid + 1] << 32);
+            mk[(size_t)(tl.y0 + tid) * L.words_per_row] = w;
+            cnt = __popcll(w.bits);
+            run = (L.word_base + (tl.y0 + tid) * L.words_per_row + (tl.x0 >> 6)) / words_per_chunk;
+        }
+        if (chunk_counts) {
+            // rows of one tile fall into very few runs: one atomic per run present
+            unsigned long long todo = __ballot(cnt > 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int r0 = __builtin_amdgcn_readlane(run, leader);
+                const bool mine = cnt > 0 && run == r0;
+                int sum = mine ? cnt : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                if (tid == leader) atomicAdd(&chunk_counts[b * kEmitMaxChunks + r0], sum);
+                todo &= ~__ballot(mine);
+            }
+        }
     }
     if (DENSE) {
         for (int r = wv; r < kTileH; r += 4) {
@@ -476,27 +497,12 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 
 // K4b: ordered emission, in three small kernels so that a frame is not tied to one workgroup.  The mask words of a
 // frame (level-major raster order) are cut into `chunks` equal runs:
-//   k_emit_count   set bits per run;
+//   (k_fast_nms)   totals the keypoints of its tile's rows into the per-run counters;
 //   k_emit_write   a workgroup per run: its base rank is the sum of the earlier runs' counts, its four wavefronts own
 //                  a quarter of the run each and append their corners at their exact rank, so the candidate list has
 //                  the order cv::FAST emits; per-level counts and score histograms are accumulated on the side;
 //   k_emit_finish  totals, and from the histograms the score of the (2*quota)-th best corner of every level: the
 //                  value KeyPointsFilter::retainBest(2*quota) keeps everything at or above.
-constexpr int kEmitMaxChunks = 64;
-
-__global__ __launch_bounds__(256) void k_emit_count(const MaskWord* __restrict__ mask, Geom g, int chunks, int per,
-                                                    int* __restrict__ chunk_counts) {
-    __shared__ int s_w[4];
-    const int b = blockIdx.y, c = blockIdx.x;
-    const MaskWord* mk = mask + (size_t)b * g.total_words;
-    const int w0 = min(c * per, g.total_words), w1 = min(w0 + per, g.total_words);
-    int mine = 0;
-    for (int word = w0 + threadIdx.x; word < w1; word += 256) mine += __popcll(mk[word].bits);
-    mine = wave_scan_incl(mine);
-    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_counts[b * kEmitMaxChunks + c] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
 
 __global__ __launch_bounds__(256) void k_emit_write(const MaskWord* __restrict__ mask, const uint8_t* __restrict__ score,
                                                     size_t atlas_bytes, Geom g, int chunks, int per,

@@ -6,6 +6,7 @@
 namespace orbx {
 
 constexpr int kMaxLevels = 16;
+constexpr int kEmitMaxChunks = 64;  // runs the mask words of a frame are cut into for the ordered emission
 constexpr int kTileW = 64;   // FAST tile: 64 x 64 level pixels per 256-thread workgroup (32 rows: more halo and barriers per pixel; 128: too few workgroups per CU)
 constexpr int kTileH = 64;
 
