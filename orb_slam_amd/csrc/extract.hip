@@ -378,7 +378,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
         const int chunks = h->emit_chunks, per = h->emit_per;
         hipLaunchKernelGGL(k_emit_write, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, chunks,
                            per, h->d_chunk_counts_p, h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_hist_p);
-        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(64), 0, s, g, chunks, h->d_chunk_counts_p,
+        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(256), 0, s, g, chunks, h->d_chunk_counts_p,
                            h->d_level_counts_p, h->d_hist_p, h->d_thresholds.p, h->d_totals.p);
     }
     T.end(ST_EMIT, s);

@@ -584,31 +584,37 @@ __global__ __launch_bounds__(256) void k_emit_write(const MaskWord* __restrict__
     if (tid < g.nlevels && lcount[tid]) atomicAdd(&level_counts[b * kMaxLevels + tid], lcount[tid]);
 }
 
-__global__ __launch_bounds__(64) void k_emit_finish(Geom g, int chunks, const int* __restrict__ chunk_counts,
-                                                    const int* __restrict__ level_counts,
-                                                    const int* __restrict__ hist_g, int* __restrict__ thresholds,
-                                                    int* __restrict__ totals) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid < g.nlevels) {
-        const int* hl = hist_g + ((size_t)b * kMaxLevels + tid) * 256;
-        const int n = level_counts[b * kMaxLevels + tid];
-        const int want = 2 * g.L[tid].quota;
+__global__ __launch_bounds__(256) void k_emit_finish(Geom g, int chunks, const int* __restrict__ chunk_counts,
+                                                     const int* __restrict__ level_counts,
+                                                     const int* __restrict__ hist_g, int* __restrict__ thresholds,
+                                                     int* __restrict__ totals) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // a wavefront per level: lane l holds bins 255-4l .. 252-4l; the threshold is the highest score s with
+    // (number of corners scoring >= s) >= 2 * quota
+    for (int l = wv; l < g.nlevels; l += 4) {
+        const int4 v = *(const int4*)(hist_g + ((size_t)b * kMaxLevels + l) * 256 + 252 - 4 * lane);
+        const int n = level_counts[b * kMaxLevels + l];
+        const int want = 2 * g.L[l].quota;
+        const int c0 = v.w, c1 = c0 + v.z, c2 = c1 + v.y, c3 = c2 + v.x;
+        const int incl = wave_scan_incl(c3);
+        const int excl = incl - c3;
         int t = 0;
         if (n > want) {
             if (want == 0) t = 256;
             else {
-                int acc = 0;
-                for (int s = 255; s >= 0; s--) {
-                    acc += hl[s];
-                    if (acc >= want) { t = s; break; }
-                }
+                const unsigned long long reach = __ballot(incl >= want);
+                const int src = __ffsll((long long)reach) - 1;  // n > want guarantees a lane reaches it
+                const int k = excl + c0 >= want ? 0 : excl + c1 >= want ? 1 : excl + c2 >= want ? 2 : 3;
+                t = __builtin_amdgcn_readlane(255 - 4 * lane - k, src);
             }
         }
-        thresholds[b * kMaxLevels + tid] = t;
+        if (lane == 0) thresholds[b * kMaxLevels + l] = t;
     }
-    int all = tid < chunks ? chunk_counts[b * kEmitMaxChunks + tid] : 0;
-    all = wave_scan_incl(all);
-    if (tid == 63) totals[b] = all;
+    if (wv == 0) {
+        int all = lane < chunks ? chunk_counts[b * kEmitMaxChunks + lane] : 0;
+        all = wave_scan_incl(all);
+        if (lane == 63) totals[b] = all;
+    }
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
         __builtin_memcpy(&v, src + (size_t)min(r, rows + 5) * aw - 4, 12);
         return v;
     };
-    constexpr int kBlurAhead = 4;
+    constexpr int kBlurAhead = 8;
     Row3 pf[kBlurAhead];
 #pragma unroll
     for (int r = 0; r < kBlurAhead; r++) pf[r] = load_row(r);
