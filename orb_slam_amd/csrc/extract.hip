@@ -284,7 +284,7 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
 orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     const Geom& g = h->geom;
     size_t A = h->atlas_bytes;
-    ORBX_TRY(h->d_atlas.ensure(A * frames + 64));  // slack: dword-wise kernels read up to 11 bytes past a span
+    ORBX_TRY(h->d_atlas.ensure(A * frames + 256));  // slack: the segment-wise kernels read up to 96 bytes past a row end
     ORBX_TRY(h->d_score.ensure(A * frames));
     ORBX_TRY(h->d_blur.ensure(A * frames + 64));
     ORBX_TRY(h->d_mask.ensure((size_t)g.total_words * frames));

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
                                                   MaskWord* __restrict__ mask, size_t atlas_bytes, Geom g,
                                                   const Tile* __restrict__ tiles, int threshold, int frame0,
                                                   int* __restrict__ chunk_counts, int words_per_chunk) {
-    __shared__ unsigned t32[kFRows * kFPitch / 4];
+    __shared__ __align__(16) unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
     __shared__ unsigned short queue[kSW * kSH];
     __shared__ unsigned s_mask[2 * kTileH];
@@ -324,18 +324,21 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     const int abase = ox & ~3, off = ox & 3;
     const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
     {
-        constexpr int kDwords = kFRows * (kFPitch / 4), kSteps = (kDwords + 255) / 256;
-        unsigned tmp[kSteps];
+        // 16-byte segments, all loads in flight before the LDS stores.  A segment may run past the end of an atlas
+        // row into the next one (or into the buffer's slack after the last row): those bytes belong to pixels
+        // outside the level's padded rectangle, which no valid pixel reads.
+        constexpr int kSegs = kFRows * (kFPitch / 16), kSteps = (kSegs + 255) / 256;
+        uint4 tmp[kSteps];
 #pragma unroll
-        for (int k = 0; k < kSteps; k++) {  // all loads in flight, then the LDS stores
-            const int i = min(tid + 256 * k, kDwords - 1);
-            const int r = i / (kFPitch / 4), c = i - r * (kFPitch / 4);
-            const int ax = min(abase + 4 * c, aw - 4), ay = min(oy + r, g.atlas_h - 1);
-            tmp[k] = *(const unsigned*)(fb + (size_t)ay * aw + ax);
+        for (int k = 0; k < kSteps; k++) {
+            const int i = min(tid + 256 * k, kSegs - 1);
+            const int r = i / (kFPitch / 16), c = i - r * (kFPitch / 16);
+            const int ay = min(oy + r, g.atlas_h - 1);
+            tmp[k] = load_u128_any(fb + (size_t)ay * aw + abase + 16 * c);
         }
 #pragma unroll
         for (int k = 0; k < kSteps; k++)
-            if (tid + 256 * k < kDwords) t32[tid + 256 * k] = tmp[k];
+            if (tid + 256 * k < kSegs) ((uint4*)t32)[tid + 256 * k] = tmp[k];
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
     if (tid < 2 * kTileH) {
