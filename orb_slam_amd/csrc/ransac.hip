@@ -44,18 +44,36 @@ orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref,
     hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, h->d_pn.p, h->d_rn.p, h->d_T.p);
     T.end(RT_NORMALIZE, s);
     T.begin(RT_SOLVE, s);
-    hipLaunchKernelGGL(k_solve_f, dim3(div_up(iterations, 64), pairs), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n,
-                       h->d_T.p, d_sets8, iterations, h->d_Fall.p);
-    hipLaunchKernelGGL(k_solve_h, dim3(div_up(iterations, 64), pairs), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n,
-                       h->d_T.p, d_sets8, iterations, h->d_Hall.p, h->d_Hiall.p);
+    const int hyp_blocks64 = (int)(((long long)pairs * iterations + 63) / 64);
+    hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
+                       iterations, pairs, h->d_Fall.p);
+    hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
+                       iterations, pairs, h->d_Hall.p, h->d_Hiall.p);
     T.end(RT_SOLVE, s);
+    // a 256-hypothesis workgroup spans at most kScorePairs pairs when iterations >= 86; below that, one launch
+    // per group of pairs would be needed - the scorers then simply run pair by pair
+    const bool flat = iterations >= 86;
+    const int score_blocks = flat ? (int)(((long long)pairs * iterations + 255) / 256) : div_up(iterations, 256);
     T.begin(RT_SCORE_F, s);
-    hipLaunchKernelGGL(k_score_f, dim3(div_up(iterations, 256), pairs), dim3(256), 0, s, d_points, d_ref, n,
-                       h->d_Fall.p, iterations, sigma, h->d_sf.p);
+    if (flat)
+        hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, iterations,
+                           pairs, sigma, h->d_sf.p);
+    else
+        for (int p = 0; p < pairs; p++)
+            hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points + (size_t)p * n * 2,
+                               d_ref + (size_t)p * n * 2, n, h->d_Fall.p + (size_t)p * iterations * 9, iterations, 1,
+                               sigma, h->d_sf.p + (size_t)p * iterations);
     T.end(RT_SCORE_F, s);
     T.begin(RT_SCORE_H, s);
-    hipLaunchKernelGGL(k_score_h, dim3(div_up(iterations, 256), pairs), dim3(256), 0, s, d_points, d_ref, n,
-                       h->d_Hall.p, h->d_Hiall.p, iterations, sigma, h->d_sh.p);
+    if (flat)
+        hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, h->d_Hall.p,
+                           h->d_Hiall.p, iterations, pairs, sigma, h->d_sh.p);
+    else
+        for (int p = 0; p < pairs; p++)
+            hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, s, d_points + (size_t)p * n * 2,
+                               d_ref + (size_t)p * n * 2, n, h->d_Hall.p + (size_t)p * iterations * 9,
+                               h->d_Hiall.p + (size_t)p * iterations * 9, iterations, 1, sigma,
+                               h->d_sh.p + (size_t)p * iterations);
     T.end(RT_SCORE_H, s);
     T.begin(RT_SELECT, s);
     hipLaunchKernelGGL(k_select, dim3(pairs, 2), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, h->d_Hall.p,

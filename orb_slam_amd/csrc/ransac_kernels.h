@@ -314,10 +314,11 @@ __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts,
 // (Initializer.cpp:336-345).
 __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
                                                 const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
-                                                int iterations, float* __restrict__ F_all) {
-    const int it = blockIdx.x * 64 + threadIdx.x;
-    const int pair = blockIdx.y;
-    if (it >= iterations) return;
+                                                int iterations, int pairs, float* __restrict__ F_all) {
+    // hypotheses of all pairs are numbered through, so wavefronts stay full when `iterations` is no multiple of 64
+    const long long hyp = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (hyp >= (long long)pairs * iterations) return;
+    const int pair = (int)(hyp / iterations), it = (int)(hyp - (long long)pair * iterations);
     const float* pn = pts_n + (size_t)pair * n * 2;
     const float* rn = ref_n + (size_t)pair * n * 2;
     const uint32_t* set = sets8 + ((size_t)pair * iterations + it) * 8;
@@ -379,11 +380,12 @@ __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n,
 // inverse and scaling of Initializer::findHomographyMat (Initializer.cpp:476-486).
 __global__ __launch_bounds__(64) void k_solve_h(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
                                                 const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
-                                                int iterations, float* __restrict__ H_all,
+                                                int iterations, int pairs, float* __restrict__ H_all,
                                                 float* __restrict__ Hinv_all) {
-    const int it = blockIdx.x * 64 + threadIdx.x;
-    const int pair = blockIdx.y;
-    if (it >= iterations) return;
+    // hypotheses of all pairs are numbered through, so wavefronts stay full when `iterations` is no multiple of 64
+    const long long hyp = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (hyp >= (long long)pairs * iterations) return;
+    const int pair = (int)(hyp / iterations), it = (int)(hyp - (long long)pair * iterations);
     const float* pn = pts_n + (size_t)pair * n * 2;
     const float* rn = ref_n + (size_t)pair * n * 2;
     const uint32_t* set = sets8 + ((size_t)pair * iterations + it) * 8;
@@ -431,35 +433,64 @@ __global__ __launch_bounds__(64) void k_solve_h(const float* __restrict__ pts_n,
     }
 }
 
-constexpr int kScoreChunk = 2048;  // correspondences staged in LDS at a time (32 KB)
+constexpr int kScoreChunk = 512;    // correspondences per pair staged in LDS at a time
+constexpr int kScorePairs = 4;      // pairs a 256-hypothesis workgroup may span (iterations >= 86)
+
+// Hypotheses of all pairs are numbered through (hyp = pair * iterations + iteration) and a workgroup takes 256
+// consecutive ones, so wavefronts stay full when `iterations` is no multiple of 64; it stages the correspondences
+// of the (at most kScorePairs) pairs it spans, and every lane walks its own pair's points in index order.
+struct ScoreSpan {
+    int pair, it, slot, p_first, n_pairs;
+    bool live;
+};
+
+__device__ __forceinline__ ScoreSpan score_span(int iterations, int pairs) {
+    ScoreSpan sp;
+    const long long h0 = (long long)blockIdx.x * 256, total = (long long)pairs * iterations;
+    const long long hyp = h0 + threadIdx.x;
+    sp.live = hyp < total;
+    const long long hc = sp.live ? hyp : total - 1;
+    sp.pair = (int)(hc / iterations);
+    sp.it = (int)(hc - (long long)sp.pair * iterations);
+    sp.p_first = (int)(h0 / iterations);
+    const int p_last = (int)(min(h0 + 255, total - 1) / iterations);
+    sp.n_pairs = p_last - sp.p_first + 1;
+    sp.slot = sp.pair - sp.p_first;
+    return sp;
+}
+
+__device__ __forceinline__ void score_stage(float4 (*s_pt)[kScoreChunk], const ScoreSpan& sp, const float* pts,
+                                            const float* ref, int n, int base, int cnt) {
+    for (int i = threadIdx.x; i < cnt * sp.n_pairs; i += 256) {
+        const int q = i / cnt, j = i - q * cnt;
+        const float2* p2 = (const float2*)(pts + (size_t)(sp.p_first + q) * n * 2);
+        const float2* r2 = (const float2*)(ref + (size_t)(sp.p_first + q) * n * 2);
+        const float2 a = r2[base + j], b = p2[base + j];
+        s_pt[q][j] = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
 
 // K12F: Initializer::checkFundamentalScore (Initializer.cpp:369-444) for one hypothesis per lane; fp64.
 __global__ __launch_bounds__(256) void k_score_f(const float* __restrict__ pts, const float* __restrict__ ref, int n,
-                                                 const float* __restrict__ F_all, int iterations, double sigma,
-                                                 float* __restrict__ score_out) {
-    __shared__ float4 s_pt[kScoreChunk];
-    const int it = blockIdx.x * 256 + threadIdx.x;
-    const int pair = blockIdx.y;
-    const bool live = it < iterations;
-    const float* Fp = F_all + ((size_t)pair * iterations + (live ? it : 0)) * 9;
+                                                 const float* __restrict__ F_all, int iterations, int pairs,
+                                                 double sigma, float* __restrict__ score_out) {
+    __shared__ float4 s_pt[kScorePairs][kScoreChunk];
+    const ScoreSpan sp = score_span(iterations, pairs);
+    const bool live = sp.live;
+    const float* Fp = F_all + ((size_t)sp.pair * iterations + sp.it) * 9;
     const double f11 = Fp[0], f12 = Fp[1], f13 = Fp[2], f21 = Fp[3], f22 = Fp[4], f23 = Fp[5], f31 = Fp[6],
                  f32 = Fp[7], f33 = Fp[8];
     double score = 0;
     const double th = 3.841, th_score = 5.991;
     const double inv_sigma_square = 1.0 / (sigma * sigma);
-    const float2* p2 = (const float2*)(pts + (size_t)pair * n * 2);
-    const float2* r2 = (const float2*)(ref + (size_t)pair * n * 2);
     for (int base = 0; base < n; base += kScoreChunk) {
         const int cnt = min(kScoreChunk, n - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            const float2 a = r2[base + i], b = p2[base + i];
-            s_pt[i] = make_float4(a.x, a.y, b.x, b.y);
-        }
+        score_stage(s_pt, sp, pts, ref, n, base, cnt);
         __syncthreads();
         if (live)
             for (int i = 0; i < cnt; i++) {
-                const float4 q = s_pt[i];
+                const float4 q = s_pt[sp.slot][i];
                 const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
                 const double a2 = f11 * u1 + f12 * v1 + f13;
                 const double b2 = f21 * u1 + f22 * v1 + f23;
@@ -477,20 +508,20 @@ __global__ __launch_bounds__(256) void k_score_f(const float* __restrict__ pts, 
                 if (!(chi2 > th)) score += th_score - chi2;
             }
     }
-    if (live) score_out[(size_t)pair * iterations + it] = (float)score;
+    if (live) score_out[(size_t)sp.pair * iterations + sp.it] = (float)score;
 }
 
 // K12H: Initializer::checkHomographyScore (Initializer.cpp:501-585); fp32 with the double reciprocal of the
 // reference (`1.0 / (float expression)` narrowed to float).
 __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, const float* __restrict__ ref, int n,
                                                  const float* __restrict__ H_all, const float* __restrict__ Hinv_all,
-                                                 int iterations, double sigma, float* __restrict__ score_out) {
-    __shared__ float4 s_pt[kScoreChunk];
-    const int it = blockIdx.x * 256 + threadIdx.x;
-    const int pair = blockIdx.y;
-    const bool live = it < iterations;
-    const float* Hp = H_all + ((size_t)pair * iterations + (live ? it : 0)) * 9;
-    const float* Ip = Hinv_all + ((size_t)pair * iterations + (live ? it : 0)) * 9;
+                                                 int iterations, int pairs, double sigma,
+                                                 float* __restrict__ score_out) {
+    __shared__ float4 s_pt[kScorePairs][kScoreChunk];
+    const ScoreSpan sp = score_span(iterations, pairs);
+    const bool live = sp.live;
+    const float* Hp = H_all + ((size_t)sp.pair * iterations + sp.it) * 9;
+    const float* Ip = Hinv_all + ((size_t)sp.pair * iterations + sp.it) * 9;
     const float h11 = Hp[0], h12 = Hp[1], h13 = Hp[2], h21 = Hp[3], h22 = Hp[4], h23 = Hp[5], h31 = Hp[6], h32 = Hp[7],
                 h33 = Hp[8];
     const float i11 = Ip[0], i12 = Ip[1], i13 = Ip[2], i21 = Ip[3], i22 = Ip[4], i23 = Ip[5], i31 = Ip[6], i32 = Ip[7],
@@ -498,19 +529,14 @@ __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, 
     float score = 0;
     const float th = 5.991;
     const float invSigmaSquare = 1.0 / (sigma * sigma);
-    const float2* p2 = (const float2*)(pts + (size_t)pair * n * 2);
-    const float2* r2 = (const float2*)(ref + (size_t)pair * n * 2);
     for (int base = 0; base < n; base += kScoreChunk) {
         const int cnt = min(kScoreChunk, n - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            const float2 a = r2[base + i], b = p2[base + i];
-            s_pt[i] = make_float4(a.x, a.y, b.x, b.y);
-        }
+        score_stage(s_pt, sp, pts, ref, n, base, cnt);
         __syncthreads();
         if (live)
             for (int i = 0; i < cnt; i++) {
-                const float4 q = s_pt[i];
+                const float4 q = s_pt[sp.slot][i];
                 const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
                 const float w2in1inv = 1.0 / (i31 * u2 + i32 * v2 + i33);
                 const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
@@ -526,7 +552,7 @@ __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, 
                 if (!(chi2 > th)) score += th - chi2;
             }
     }
-    if (live) score_out[(size_t)pair * iterations + it] = score;
+    if (live) score_out[(size_t)sp.pair * iterations + sp.it] = score;
 }
 
 // Winner selection and inlier flags.  The reference keeps a hypothesis when (float)score > best (strict), best
