@@ -264,15 +264,28 @@ __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts,
     const int pair = blockIdx.x, side = blockIdx.y, lane = threadIdx.x;
     const float* in = (side == 0 ? pts : ref) + (size_t)pair * n * 2;
     float* out = (side == 0 ? pts_n : ref_n) + (size_t)pair * n * 2;
-    if (lane == 0) {
+    {
+        // the coordinate sums run in index order on lane 0 (float addition is not associative); the wavefront
+        // feeds it through LDS, 512 points at a time, so the serial part never waits on memory
+        float2* s_xy = (float2*)s_norm;  // 1024 doubles = room for 1024 float2
         float sx = 0.f, sy = 0.f;
-        for (int i = 0; i < n; i++) {
-            sx = sx + in[2 * i];
-            sy = sy + in[2 * i + 1];
+        for (int base = 0; base < n; base += 1024) {
+            const int cnt = min(1024, n - base);
+            for (int i = lane; i < cnt; i += 64) s_xy[i] = ((const float2*)in)[base + i];
+            __syncthreads();
+            if (lane == 0)
+                for (int i = 0; i < cnt; i++) {
+                    const float2 p = s_xy[i];
+                    sx = sx + p.x;
+                    sy = sy + p.y;
+                }
+            __syncthreads();
         }
-        const double n_inv = 1.0 / n;
-        s_bcast[0] = sx * n_inv;
-        s_bcast[1] = sy * n_inv;
+        if (lane == 0) {
+            const double n_inv = 1.0 / n;
+            s_bcast[0] = sx * n_inv;
+            s_bcast[1] = sy * n_inv;
+        }
     }
     __syncthreads();
     const double mean_x = s_bcast[0], mean_y = s_bcast[1];
