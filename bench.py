@@ -135,12 +135,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ORBX_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_device = device if backend == "nccl" else torch.device("cpu")
     B = args.frames
     base = np.load(os.path.join(ROOT, "tests", "golden", "test_images.npz"))["bgr1"]
     frames, homs = make_sequence(torch, base, B, rank * B, device)
@@ -240,7 +247,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -312,7 +319,7 @@ def main():
         barrier()
         rdt = time.perf_counter() - r0
         if world > 1:
-            t = torch.tensor([rdt], dtype=torch.float64, device=device)
+            t = torch.tensor([rdt], dtype=torch.float64, device=red_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rdt = float(t.item())
         ransac = {"hypotheses_per_s": world * P * it * 2 * reps / rdt, "pairs": P, "iterations": it,
