@@ -9,6 +9,7 @@
  * (src/frame.cpp:394-422) compile unchanged against them.
  */
 #pragma once
+#include <algorithm>
 
 #include <memory>
 #include <string>
@@ -147,6 +148,57 @@ public:
                 depth.data(), ref_desc.data, sf.data(), (int)sf.size(), level_mode, radius, check_orientation ? 1 : 0,
                 reinterpret_cast<orbx_match*>(out.data()), &count),
             "ORBMatcher::matchByProjection");
+        matches.insert(matches.end(), out.begin(), out.begin() + count);
+    }
+
+    /**
+     * BoW matcher (orb_matcher.cpp:735-746, 354-368, 386-497): features of `frame` against those of the key frame
+     * that fall into the same vocabulary node; a reference feature takes part only if it has a map point that is
+     * not bad.  The frame types provide featuresUndist(), descriptorsUndist() and bowFeatures() (an ordered map
+     * node id -> feature indices, as DBoW2::FeatureVector is), the key frame frame() and obsMapPoints().
+     */
+    template <typename FramePtrT, typename KeyFramePtrT>
+    void matchByBowFeatures(
+        const FramePtrT& frame,
+        const KeyFramePtrT& ref_key_frame,
+        std::vector<cv::DMatch>& matches,
+        const bool check_orientation = true,
+        const float nn_ratio = 0.6) const
+    {
+        const auto& ref_frame = ref_key_frame->frame();
+        const auto ref_map_points = ref_key_frame->obsMapPoints();
+        const auto& key_points = frame->featuresUndist();
+        const auto& ref_key_points = ref_frame->featuresUndist();
+        const cv::Mat& descs = frame->descriptorsUndist();
+        const cv::Mat& ref_descs = ref_frame->descriptorsUndist();
+        const int n = (int)key_points.size(), n_ref = (int)ref_key_points.size();
+        std::vector<uint8_t> has(n_ref, 0);
+        for (int i = 0; i < n_ref && i < (int)ref_map_points.size(); ++i)
+            has[i] = ref_map_points[i] && !ref_map_points[i]->isBad();
+        auto flatten = [](const auto& fv, std::vector<uint32_t>& ids, std::vector<int32_t>& start,
+                          std::vector<int32_t>& items) {
+            start.push_back(0);
+            for (const auto& node : fv) {
+                ids.push_back((uint32_t)node.first);
+                for (auto i : node.second) items.push_back((int32_t)i);
+                start.push_back((int32_t)items.size());
+            }
+        };
+        std::vector<uint32_t> ids, ref_ids;
+        std::vector<int32_t> start, items, ref_start, ref_items;
+        flatten(frame->bowFeatures(), ids, start, items);
+        flatten(ref_frame->bowFeatures(), ref_ids, ref_start, ref_items);
+        std::vector<cv::DMatch> out(std::max(n, 1));
+        int count = 0;
+        const int low_threshold = 50;  // orb_matcher.h:201
+        orbx_compat::check(
+            orbx_match_bow(
+                handle_.get(), reinterpret_cast<const orbx_keypoint*>(key_points.data()), n, descs.data,
+                reinterpret_cast<const orbx_keypoint*>(ref_key_points.data()), n_ref, ref_descs.data, has.data(),
+                ids.data(), start.data(), items.data(), (int)ids.size(), ref_ids.data(), ref_start.data(),
+                ref_items.data(), (int)ref_ids.size(), low_threshold, nn_ratio, check_orientation ? 1 : 0,
+                reinterpret_cast<orbx_match*>(out.data()), &count),
+            "ORBMatcher::matchByBowFeatures");
         matches.insert(matches.end(), out.begin(), out.begin() + count);
     }
 

@@ -200,6 +200,18 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
                                               int level_mode, float radius, int check_orientation,
                                               int32_t* d_matched, int32_t* d_distance, int32_t* d_n_matches);
 
+/* Replaces BowOrbMatcher::match (orb_matcher.cpp:386-497).  The two DBoW2::FeatureVector maps (node id -> feature
+   indices) are passed as CSR arrays with ascending node ids: node_ids[n_nodes], node_start[n_nodes + 1],
+   node_items[node_start[n_nodes]].  ref_has_point[i] = reference feature i has a map point that is not bad.
+   low_threshold / nn_ratio / check_orientation are the matcher's members (orb_matcher.h:197-201: 50, 0.6, true). */
+orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int n, const uint8_t* descriptors,
+                           const orbx_keypoint* ref_keypoints, int n_ref, const uint8_t* ref_descriptors,
+                           const uint8_t* ref_has_point, const uint32_t* node_ids, const int32_t* node_start,
+                           const int32_t* node_items, int n_nodes, const uint32_t* ref_node_ids,
+                           const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes,
+                           int low_threshold, float nn_ratio, int check_orientation, orbx_match* matches,
+                           int* count);
+
 /* Replaces BruteForceWithProjectionMatcher::match(frame, points_3d, matches) (orb_matcher.cpp:257-352) with the
    track properties (Frame::isInCameraView, frame.cpp:220-268) supplied by the caller. */
 orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,

@@ -277,4 +277,62 @@ int orc_match_projection_points(const orc_grid_params* g, const int32_t* cell_st
     return create_matches(matched, feature_dists, out);
 }
 
+/* BowOrbMatcher::match, orb_matcher.cpp:386-497.  The two DBoW2::FeatureVector maps (node id -> feature indices,
+   ascending node id) arrive as CSR arrays; the lower_bound jumps of the reference visit exactly the common nodes in
+   ascending order.  ref_has_mp[i] = "reference feature i has a map point that is not bad". */
+int orc_match_bow(const orc_keypoint* kps, int n, const uint8_t* desc, const orc_keypoint* ref_kps, int n_ref,
+                  const uint8_t* ref_desc, const uint8_t* ref_has_mp, const uint32_t* node_ids,
+                  const int32_t* node_start, const int32_t* node_items, int n_nodes, const uint32_t* ref_node_ids,
+                  const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
+                  float nn_ratio, int check_orientation, orc_match* out) {
+    (void)n_ref;
+    const int hist_length = 30;
+    std::vector<int> matched(n, -1), feature_dists(n, -1);
+    std::vector<std::vector<int>> rot_hist(hist_length);
+    const float factor = 1.0f / hist_length;
+    int f = 0, rf = 0;
+    while (rf < n_ref_nodes && f < n_nodes) {
+        if (ref_node_ids[rf] == node_ids[f]) {
+            for (int a = ref_node_start[rf]; a < ref_node_start[rf + 1]; ++a) {
+                const int ref_idx = ref_node_items[a];
+                if (!ref_has_mp[ref_idx]) continue;
+                int min_dist = 256, min_dist_2 = 256, matched_idx = -1;
+                for (int b = node_start[f]; b < node_start[f + 1]; ++b) {
+                    const int idx = node_items[b];
+                    if (matched[idx] > 0) continue;
+                    const int d = orc_descriptor_distance(ref_desc + (size_t)ref_idx * 32, desc + (size_t)idx * 32);
+                    if (d <= min_dist) { min_dist = d; matched_idx = idx; }
+                    else if (d < min_dist_2) min_dist_2 = d;
+                }
+                if (min_dist <= low_threshold && (float)min_dist < nn_ratio * (float)min_dist_2) {
+                    matched[matched_idx] = ref_idx;
+                    feature_dists[matched_idx] = min_dist;
+                    if (check_orientation) {
+                        float rot_diff = ref_kps[ref_idx].angle - kps[matched_idx].angle;
+                        if (rot_diff < 0.0) rot_diff += 360.0f;
+                        int bin = round(rot_diff * factor);
+                        if (bin == hist_length) bin = 0;
+                        rot_hist[bin].push_back(matched_idx);
+                    }
+                }
+            }
+            f++;
+            rf++;
+        } else if (ref_node_ids[rf] < node_ids[f]) {
+            while (rf < n_ref_nodes && ref_node_ids[rf] < node_ids[f]) rf++; /* lower_bound */
+        } else {
+            while (f < n_nodes && node_ids[f] < ref_node_ids[rf]) f++;
+        }
+    }
+    if (check_orientation) {
+        int sizes[30], i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < hist_length; i++) sizes[i] = (int)rot_hist[i].size();
+        orc_three_maxima(sizes, hist_length, &i1, &i2, &i3);
+        for (int i = 0; i < hist_length; i++)
+            if (i != i1 && i != i2 && i != i3)
+                for (int v : rot_hist[i]) matched[v] = 0;
+    }
+    return create_matches(matched, feature_dists, out);
+}
+
 } // extern "C"

@@ -121,6 +121,13 @@ int  orc_match_projection_points(const orc_grid_params* g, const int32_t* cell_s
                                  const float* view_cos, const uint8_t* pt_desc,
                                  const float* scale_factors, float radius, float nn_ratio, orc_match* out);
 
+/* BoW matcher, orb_matcher.cpp:386-497: FeatureVector maps as CSR (node ids ascending). */
+int  orc_match_bow(const orc_keypoint* kps, int n, const uint8_t* desc, const orc_keypoint* ref_kps, int n_ref,
+                   const uint8_t* ref_desc, const uint8_t* ref_has_mp, const uint32_t* node_ids,
+                   const int32_t* node_start, const int32_t* node_items, int n_nodes, const uint32_t* ref_node_ids,
+                   const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
+                   float nn_ratio, int check_orientation, orc_match* out);
+
 /* ---- two-view geometry ---- */
 void orc_normalize_points(const float* xy, int n, float* xy_norm, float* T9);
 /* cv::SVDecomp(A, w, u, vt, MODIFY_A|FULL_UV) on CV_32F, stock (non-LAPACK) OpenCV.  u may be NULL. vt is n x n. */

@@ -284,6 +284,24 @@ def match_projection_points(g, start, items, kps, desc, in_view, proj_xy, pred_l
     return out[:n].copy()
 
 
+def match_bow(kps, desc, ref_kps, ref_desc, ref_has_mp, nodes, ref_nodes, low_threshold, nn_ratio, check_orientation):
+    """nodes / ref_nodes = (node_ids uint32 ascending, node_start int32 [n+1], node_items int32)."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+    flags = np.ascontiguousarray(ref_has_mp, np.uint8)
+    ni, ns, nit = (np.ascontiguousarray(nodes[0], np.uint32), np.ascontiguousarray(nodes[1], np.int32),
+                   np.ascontiguousarray(nodes[2], np.int32))
+    ri, rs, rit = (np.ascontiguousarray(ref_nodes[0], np.uint32), np.ascontiguousarray(ref_nodes[1], np.int32),
+                   np.ascontiguousarray(ref_nodes[2], np.int32))
+    out = np.zeros(max(len(kps), 1), MATCH_DTYPE)
+    n = lib().orc_match_bow(_p(kps), len(kps), _p(desc), _p(ref_kps), len(ref_kps), _p(ref_desc), _p(flags),
+                            _p(ni), _p(ns), _p(nit), len(ni), _p(ri), _p(rs), _p(rit), len(ri), int(low_threshold),
+                            C.c_float(nn_ratio), int(bool(check_orientation)), _p(out))
+    return out[:n].copy()
+
+
 def normalize_points(xy):
     xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
     out = np.zeros_like(xy)

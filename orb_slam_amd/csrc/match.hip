@@ -1085,6 +1085,118 @@ __global__ __launch_bounds__(64) void k_resolve_sorted(ProjArgs A) {
     if (lane == 0 && A.n_matches) *A.n_matches = cnt;
 }
 
+// ---- BoW matcher (BowOrbMatcher::match, orb_matcher.cpp:386-497) ---------------------------------------------------
+// The host intersects the two feature vectors (common nodes in ascending order) into a job list: one job per
+// reference feature of a common node, with the span of the frame's features in that node.  One wavefront walks the
+// jobs in order (the "already matched" rule makes them sequential); per job the lanes compute the Hamming distances
+// of the still-free candidates in parallel and compact them in list order, then the best / second-best walk of the
+// reference runs over that list with its own tie rules (`<=` for the best, which does not demote the old best).
+struct BowArgs {
+    const orbx_keypoint* kps;
+    int n;
+    const uint8_t* desc;
+    const orbx_keypoint* ref_kps;
+    const uint8_t* ref_desc;
+    const uint8_t* ref_flag;
+    const int32_t* jobs;   // [n_jobs][3]: reference feature, first candidate, number of candidates
+    int n_jobs;
+    const int32_t* items;  // candidate feature indices (the frame's feature vector, node after node)
+    int low_threshold;
+    float nn_ratio;
+    int check_orientation;
+    int32_t* matched;      // out [n]
+    int32_t* dists;        // out [n]
+    int32_t* pushes;       // scratch [2 * n_jobs]
+};
+
+__global__ __launch_bounds__(64) void k_bow_match(BowArgs A) {
+    extern __shared__ int32_t s_matched[];  // [n]
+    __shared__ int32_t s_idx[64];
+    __shared__ int32_t s_dist[64];
+    __shared__ int32_t s_hist[30];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < A.n; i += 64) {
+        s_matched[i] = -1;
+        A.dists[i] = -1;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    __syncthreads();
+    int n_push = 0;
+    for (int job = 0; job < A.n_jobs; job++) {
+        const int ref_idx = A.jobs[3 * job], start = A.jobs[3 * job + 1], len = A.jobs[3 * job + 2];
+        if (!A.ref_flag[ref_idx]) continue;
+        const uint8_t* rd = A.ref_desc + (size_t)ref_idx * 32;
+        int min_d = 256, min_d2 = 256, id = -1;  // the same on every lane
+        for (int cb = 0; cb < len; cb += 64) {
+            const int c = cb + lane;
+            int idx = -1, d = 0;
+            bool free_ = false;
+            if (c < len) {
+                idx = A.items[start + c];
+                free_ = !(s_matched[idx] > 0);
+                if (free_) d = hamming32(rd, A.desc + (size_t)idx * 32);
+            }
+            const unsigned long long bal = __ballot(free_);
+            if (free_) {
+                const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+                s_idx[pos] = idx;
+                s_dist[pos] = d;
+            }
+            wave_lds_fence();
+            const int cnt = __popcll(bal);
+            for (int i = 0; i < cnt; i++) {
+                const int di = s_dist[i];
+                if (di <= min_d) { min_d = di; id = s_idx[i]; }
+                else if (di < min_d2) min_d2 = di;
+            }
+            wave_lds_fence();
+        }
+        if (min_d <= A.low_threshold && (float)min_d < A.nn_ratio * (float)min_d2) {
+            if (lane == 0) {
+                s_matched[id] = ref_idx;
+                A.dists[id] = min_d;
+                if (A.check_orientation) {
+                    A.pushes[2 * n_push] = ref_idx;
+                    A.pushes[2 * n_push + 1] = id;
+                }
+            }
+            n_push++;
+            wave_lds_fence();
+        }
+    }
+    __syncthreads();
+    if (A.check_orientation) {
+        __threadfence_block();
+        const float factor = 1.0f / 30;
+        for (int i = lane; i < n_push; i += 64) {
+            float rot = A.ref_kps[A.pushes[2 * i]].angle - A.kps[A.pushes[2 * i + 1]].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin < 0 || bin >= 30) bin = -1;
+            else atomicAdd(&s_hist[bin], 1);
+            A.pushes[2 * i] = bin;
+        }
+        __syncthreads();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = lane; i < n_push; i += 64) {
+            const int bin = A.pushes[2 * i];
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) s_matched[A.pushes[2 * i + 1]] = 0;
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < A.n; i += 64) A.matched[i] = s_matched[i];
+}
+
 }  // namespace
 
 struct orbx_matcher {
@@ -1465,6 +1577,100 @@ orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, co
     return run_projection(h, 1, g, cell_start, cell_items, keypoints, n, descriptors, nullptr, n_points, in_view,
                           proj_xy, nullptr, pred_level, view_cos, point_descriptors, scale_factors, n_levels, 0,
                           radius, nn_ratio, 0, matches, count);
+}
+
+orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int n, const uint8_t* descriptors,
+                           const orbx_keypoint* ref_keypoints, int n_ref, const uint8_t* ref_descriptors,
+                           const uint8_t* ref_has_point, const uint32_t* node_ids, const int32_t* node_start,
+                           const int32_t* node_items, int n_nodes, const uint32_t* ref_node_ids,
+                           const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes,
+                           int low_threshold, float nn_ratio, int check_orientation, orbx_match* matches,
+                           int* count) {
+    if (!h || !count || n < 0 || n_ref < 0 || n_nodes < 0 || n_ref_nodes < 0) return ORBX_BAD_ARG;
+    *count = 0;
+    if (n == 0 || n_ref == 0 || n_nodes == 0 || n_ref_nodes == 0) return ORBX_OK;
+    if (!keypoints || !descriptors || !ref_keypoints || !ref_descriptors || !ref_has_point || !node_ids ||
+        !node_start || !node_items || !ref_node_ids || !ref_node_start || !ref_node_items || !matches)
+        return ORBX_BAD_ARG;
+    if (n > kMaxFeatures) return ORBX_CAPACITY;
+    // validation of everything the kernel indexes with: ascending node ids, monotone offsets, indices in range
+    auto valid = [](const uint32_t* ids, const int32_t* start, const int32_t* items, int nn, int limit) {
+        if (start[0] != 0) return false;
+        for (int i = 0; i < nn; i++) {
+            if (start[i + 1] < start[i]) return false;
+            if (i > 0 && !(ids[i - 1] < ids[i])) return false;
+        }
+        for (int i = 0; i < start[nn]; i++)
+            if (items[i] < 0 || items[i] >= limit) return false;
+        return true;
+    };
+    if (!valid(node_ids, node_start, node_items, n_nodes, n) ||
+        !valid(ref_node_ids, ref_node_start, ref_node_items, n_ref_nodes, n_ref))
+        return ORBX_BAD_ARG;
+    // the reference's walk over the two std::maps with lower_bound jumps == intersection of the sorted id lists
+    std::vector<int32_t> jobs;
+    for (int f = 0, rf = 0; f < n_nodes && rf < n_ref_nodes;) {
+        if (node_ids[f] == ref_node_ids[rf]) {
+            for (int a = ref_node_start[rf]; a < ref_node_start[rf + 1]; a++) {
+                jobs.push_back(ref_node_items[a]);
+                jobs.push_back(node_start[f]);
+                jobs.push_back(node_start[f + 1] - node_start[f]);
+            }
+            f++;
+            rf++;
+        } else if (ref_node_ids[rf] < node_ids[f]) rf++;
+        else f++;
+    }
+    const int n_jobs = (int)(jobs.size() / 3);
+    if (n_jobs == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int n_items = node_start[n_nodes];
+    ORBX_TRY(h->d_kp.ensure(n));
+    ORBX_TRY(h->d_refkp.ensure(n_ref));
+    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
+    ORBX_TRY(h->d_t.ensure((size_t)n_ref * 32));
+    ORBX_TRY(h->d_flags.ensure(n_ref));
+    ORBX_TRY(h->d_items.ensure(std::max(n_items, 1)));
+    ORBX_TRY(h->d_ints.ensure((size_t)3 * n_jobs));
+    ORBX_TRY(h->d_idx.ensure(n));
+    ORBX_TRY(h->d_dist.ensure(n));
+    ORBX_TRY(h->d_pushes.ensure((size_t)2 * n_jobs + 2));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, keypoints, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_refkp.p, ref_keypoints, sizeof(orbx_keypoint) * n_ref, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_q.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_t.p, ref_descriptors, (size_t)n_ref * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_flags.p, ref_has_point, n_ref, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_items.p, node_items, sizeof(int32_t) * n_items, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_ints.p, jobs.data(), sizeof(int32_t) * jobs.size(), hipMemcpyHostToDevice, s));
+    BowArgs A;
+    A.kps = h->d_kp.p;
+    A.n = n;
+    A.desc = h->d_q.p;
+    A.ref_kps = h->d_refkp.p;
+    A.ref_desc = h->d_t.p;
+    A.ref_flag = h->d_flags.p;
+    A.jobs = h->d_ints.p;
+    A.n_jobs = n_jobs;
+    A.items = h->d_items.p;
+    A.low_threshold = low_threshold;
+    A.nn_ratio = nn_ratio;
+    A.check_orientation = check_orientation;
+    A.matched = h->d_idx.p;
+    A.dists = h->d_dist.p;
+    A.pushes = h->d_pushes.p;
+    hipLaunchKernelGGL(k_bow_match, dim3(1), dim3(64), sizeof(int32_t) * (size_t)n, s, A);
+    ORBX_HIP(hipGetLastError());
+    std::vector<int32_t> matched(n), dists(n);
+    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    // MatcherBase::createMatches (orb_matcher.h:81-93)
+    int c = 0;
+    for (int i = 0; i < n; i++)
+        if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
+    *count = c;
+    return ORBX_OK;
 }
 
 }  // extern "C"

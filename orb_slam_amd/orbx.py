@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -353,6 +353,26 @@ class Matcher:
                                                   _p(view_cos), _p(pt_desc), _p(sf), len(sf), C.c_float(radius),
                                                   C.c_float(nn_ratio), _p(out), C.byref(n)),
                "orbx_match_projection_points")
+        return out[:n.value].copy()
+
+    def match_bow(self, kps, desc, ref_kps, ref_desc, ref_has_point, nodes, ref_nodes, low_threshold=50, nn_ratio=0.6,
+                  check_orientation=True):
+        """nodes / ref_nodes = (node_ids uint32 ascending, node_start int32 [n+1], node_items int32)."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+        flags = np.ascontiguousarray(ref_has_point, np.uint8)
+        ni, ns, nit = (np.ascontiguousarray(nodes[0], np.uint32), np.ascontiguousarray(nodes[1], np.int32),
+                       np.ascontiguousarray(nodes[2], np.int32))
+        ri, rs, rit = (np.ascontiguousarray(ref_nodes[0], np.uint32), np.ascontiguousarray(ref_nodes[1], np.int32),
+                       np.ascontiguousarray(ref_nodes[2], np.int32))
+        out = np.zeros(max(len(kps), 1), MATCH_DTYPE)
+        n = C.c_int()
+        _check(lib().orbx_match_bow(self._h, _p(kps), len(kps), _p(desc), _p(ref_kps), len(ref_kps), _p(ref_desc),
+                                    _p(flags), _p(ni), _p(ns), _p(nit), len(ni), _p(ri), _p(rs), _p(rit), len(ri),
+                                    int(low_threshold), C.c_float(nn_ratio), int(bool(check_orientation)), _p(out),
+                                    C.byref(n)), "orbx_match_bow")
         return out[:n.value].copy()
 
 

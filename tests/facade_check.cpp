@@ -4,8 +4,28 @@
 #include <orb_slam/geometry/orb_matcher.h>
 #include <orb_slam/initializer.h>
 
+#include <map>
+#include <memory>
+
 using namespace orb_slam;
 using namespace orb_slam::geometry;
+
+// the slice of Frame / KeyFrame / MapPoint that ORBMatcher::matchByBowFeatures touches
+struct MockMapPoint { bool bad = false; bool isBad() const { return bad; } };
+struct MockFrame {
+    std::vector<cv::KeyPoint> kps;
+    cv::Mat desc;
+    std::map<unsigned, std::vector<unsigned>> bow;
+    const std::vector<cv::KeyPoint>& featuresUndist() const { return kps; }
+    const cv::Mat& descriptorsUndist() const { return desc; }
+    const std::map<unsigned, std::vector<unsigned>>& bowFeatures() const { return bow; }
+};
+struct MockKeyFrame {
+    std::shared_ptr<MockFrame> f;
+    std::vector<std::shared_ptr<MockMapPoint>> mps;
+    const std::shared_ptr<MockFrame>& frame() const { return f; }
+    std::vector<std::shared_ptr<MockMapPoint>> obsMapPoints() const { return mps; }
+};
 
 int main(int argc, char** argv) {
     ros::NodeHandle nh;
@@ -30,6 +50,17 @@ int main(int argc, char** argv) {
     std::vector<cv::DMatch> m;
     mt.match(d1, d2, m, true);
     std::printf("kp=%zu desc=%d matches=%zu levels=%d sf1=%.9g\n", k1.size(), d1.rows, m.size(), ex.levels(), ex.scaleFactors()[1]);
+    {
+        auto fa = std::make_shared<MockFrame>(), fb = std::make_shared<MockFrame>();
+        fa->kps = k1; fa->desc = d1; fb->kps = k2; fb->desc = d2;
+        for (unsigned i = 0; i < (unsigned)k1.size(); i++) { fa->bow[d1.data[32 * i] % 37u].push_back(i); fb->bow[d2.data[32 * i] % 37u].push_back(i); }
+        auto kf = std::make_shared<MockKeyFrame>();
+        kf->f = fb;
+        for (size_t i = 0; i < k2.size(); i++) kf->mps.push_back(i % 5 ? std::make_shared<MockMapPoint>() : nullptr);
+        std::vector<cv::DMatch> mb;
+        mt.matchByBowFeatures(fa, kf, mb, true, 0.6f);
+        std::printf("bow_matches=%zu\n", mb.size());
+    }
     Initializer init(1.0, 50);
     std::vector<cv::Point2f> p, r;
     for (auto& mm : m) { p.push_back(k1[mm.queryIdx].pt); r.push_back(k2[mm.trainIdx].pt); }

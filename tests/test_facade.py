@@ -33,3 +33,4 @@ def test_facade_runs_on_gpu():
     kp = int(out.split("kp=")[1].split()[0])
     assert kp > 300 and f"desc={kp}" in out and f"matches=" in out
     assert "sf1=1.20000005" in out
+    assert int(out.split("bow_matches=")[1].split()[0]) > kp // 2

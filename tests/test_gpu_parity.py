@@ -475,3 +475,44 @@ def test_4k_extraction_bit_exact(oracle):
         assert np.array_equal(kps[f, :counts[f]], ora[f][1].astype(orbx.KP_DTYPE))
         assert np.array_equal(desc[f, :counts[f]], ora[f][2])
     ex.close()
+
+
+def _feature_vector(desc, rng, n_nodes, drop=0.0):
+    """A stand-in for DBoW2::FeatureVector: node id from a few descriptor bits (so matching features tend to share
+    a node), ascending node ids, feature indices in ascending order inside a node; some nodes removed."""
+    node = (desc[:, 0].astype(np.uint32) * 7 + desc[:, 5]) % n_nodes * 13 + 5
+    ids = np.unique(node)
+    if drop > 0:
+        ids = ids[rng.uniform(size=len(ids)) >= drop]
+    start, items = [0], []
+    for i in ids:
+        idx = np.nonzero(node == i)[0]
+        items.extend(idx.tolist())
+        start.append(len(items))
+    return ids.astype(np.uint32), np.array(start, np.int32), np.array(items, np.int32)
+
+
+def test_bow_matcher_bit_exact(oracle, matcher, ex1000, test_images):
+    """BowOrbMatcher::match (orb_matcher.cpp:386-497) with synthetic feature vectors, against the oracle."""
+    rng = np.random.default_rng(61)
+    k0, d0 = ex1000.compute(test_images[0], ex1000.detect(test_images[0]))
+    k1, d1 = ex1000.compute(test_images[1], ex1000.detect(test_images[1]))
+    d1 = d1.copy()
+    take = rng.choice(len(d1), min(len(d0), len(d1)) // 2, replace=False)
+    d1[take] = d0[take % len(d0)] ^ (rng.uniform(size=(len(take), 32)) < 0.03).astype(np.uint8)  # near-duplicates
+    has = (rng.uniform(size=len(k1)) > 0.15).astype(np.uint8)
+    for n_nodes, drop in ((8, 0.0), (40, 0.2), (300, 0.3)):
+        nodes = _feature_vector(d0, rng, n_nodes, drop)
+        ref_nodes = _feature_vector(d1, rng, n_nodes, drop)
+        for low, ratio, orient in ((50, 0.6, True), (80, 0.9, False), (30, 0.75, True)):
+            m = matcher.match_bow(k0, d0, k1, d1, has, nodes, ref_nodes, low, ratio, orient)
+            om = oracle.match_bow(k0, d0, k1, d1, has, nodes, ref_nodes, low, ratio, orient)
+            assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE)), (n_nodes, low, ratio, orient)
+        if n_nodes == 8:
+            assert len(m) > 30
+    # no common node / empty vectors
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    assert len(matcher.match_bow(k0, d0, k1, d1, has, e, ref_nodes)) == 0
+    bad = (nodes[0][::-1].copy(), nodes[1], nodes[2])
+    with pytest.raises(orbx.OrbxError):
+        matcher.match_bow(k0, d0, k1, d1, has, bad, ref_nodes)
