@@ -212,6 +212,13 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
                            int low_threshold, float nn_ratio, int check_orientation, orbx_match* matches,
                            int* count);
 
+/* Replaces the arithmetic of MapPoint::computeBestDescriptor (src/map_point.cpp:109-166) for a batch of map points:
+   the observed descriptors of point p are rows point_start[p] .. point_start[p + 1] of `descriptors` (32 bytes
+   each, at most 1024 per point); best_index[p] = the row inside the set with the least median Hamming distance to
+   the set (first such row), -1 for an empty set. */
+orbx_status orbx_best_descriptor_batch(orbx_matcher* h, const uint8_t* descriptors, const int32_t* point_start,
+                                       int n_points, int32_t* best_index);
+
 /* Replaces BruteForceWithProjectionMatcher::match(frame, points_3d, matches) (orb_matcher.cpp:257-352) with the
    track properties (Frame::isInCameraView, frame.cpp:220-268) supplied by the caller. */
 orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start,

@@ -335,4 +335,29 @@ int orc_match_bow(const orc_keypoint* kps, int n, const uint8_t* desc, const orc
     return create_matches(matched, feature_dists, out);
 }
 
+/* MapPoint::computeBestDescriptor, map_point.cpp:109-166, for n_points descriptor sets laid out back to back
+   (point p owns rows point_start[p] .. point_start[p+1]).  best[p] = row inside the set, -1 for an empty set. */
+void orc_best_descriptor(const uint8_t* desc, const int32_t* point_start, int n_points, int32_t* best) {
+    for (int p = 0; p < n_points; p++) {
+        const uint8_t* d = desc + (size_t)point_start[p] * 32;
+        const int n = point_start[p + 1] - point_start[p];
+        if (n <= 0) { best[p] = -1; continue; }
+        std::vector<std::vector<float>> distances(n, std::vector<float>(n, 0.f));
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++) {
+                int dist = orc_descriptor_distance(d + (size_t)i * 32, d + (size_t)j * 32);
+                distances[i][j] = (float)dist;
+                distances[j][i] = (float)dist;
+            }
+        int best_median = 2147483647, best_idx = 0;
+        for (int i = 0; i < n; i++) {
+            std::vector<int> dists(distances[i].begin(), distances[i].end());
+            std::sort(dists.begin(), dists.end());
+            int median = dists[(size_t)(0.5 * (n - 1))];
+            if (median < best_median) { best_median = median; best_idx = i; }
+        }
+        best[p] = best_idx;
+    }
+}
+
 } // extern "C"

@@ -128,6 +128,9 @@ int  orc_match_bow(const orc_keypoint* kps, int n, const uint8_t* desc, const or
                    const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
                    float nn_ratio, int check_orientation, orc_match* out);
 
+/* MapPoint::computeBestDescriptor (map_point.cpp:109-166) over descriptor sets laid out back to back. */
+void orc_best_descriptor(const uint8_t* desc, const int32_t* point_start, int n_points, int32_t* best);
+
 /* ---- two-view geometry ---- */
 void orc_normalize_points(const float* xy, int n, float* xy_norm, float* T9);
 /* cv::SVDecomp(A, w, u, vt, MODIFY_A|FULL_UV) on CV_32F, stock (non-LAPACK) OpenCV.  u may be NULL. vt is n x n. */

@@ -302,6 +302,14 @@ def match_bow(kps, desc, ref_kps, ref_desc, ref_has_mp, nodes, ref_nodes, low_th
     return out[:n].copy()
 
 
+def best_descriptor(desc, point_start):
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ps = np.ascontiguousarray(point_start, np.int32)
+    best = np.zeros(max(len(ps) - 1, 1), np.int32)
+    lib().orc_best_descriptor(_p(desc), _p(ps), len(ps) - 1, _p(best))
+    return best[:len(ps) - 1].copy()
+
+
 def normalize_points(xy):
     xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
     out = np.zeros_like(xy)

@@ -1197,6 +1197,47 @@ __global__ __launch_bounds__(64) void k_bow_match(BowArgs A) {
     for (int i = lane; i < A.n; i += 64) A.matched[i] = s_matched[i];
 }
 
+// ---- MapPoint::computeBestDescriptor (map_point.cpp:109-166), batched ---------------------------------------------
+// One wavefront per map point.  For every observation i the Hamming distances to all observations of the point are
+// laid out in LDS; the median the reference reads after sorting, element (int)(0.5 * (n - 1)), is the value v with
+// #(d < v) <= k < #(d <= v), found by counting; the first i with the smallest median wins (`<`).
+constexpr int kBestMaxObs = 1024;
+__global__ __launch_bounds__(64) void k_best_descriptor(const uint8_t* __restrict__ desc,
+                                                        const int32_t* __restrict__ point_start, int n_points,
+                                                        int32_t* __restrict__ best) {
+    __shared__ int s_d[kBestMaxObs];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n_points) return;
+    const int first = point_start[p], n = point_start[p + 1] - first;
+    if (n <= 0) {
+        if (lane == 0) best[p] = -1;
+        return;
+    }
+    const uint8_t* d = desc + (size_t)first * 32;
+    const int k = (int)(0.5 * (n - 1));
+    int best_median = 0x7fffffff, best_idx = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = lane; j < n; j += 64) s_d[j] = j == i ? 0 : hamming32(d + (size_t)i * 32, d + (size_t)j * 32);
+        wave_lds_fence();
+        int median = -1;
+        for (int j = lane; j < n; j += 64) {
+            const int v = s_d[j];
+            int less = 0, leq = 0;
+            for (int t = 0; t < n; t++) {
+                const int o = s_d[t];
+                less += o < v;
+                leq += o <= v;
+            }
+            if (less <= k && k < leq) median = v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) median = max(median, __shfl_xor(median, o));
+        if (median < best_median) { best_median = median; best_idx = i; }
+        wave_lds_fence();
+    }
+    if (lane == 0) best[p] = best_idx;
+}
+
 }  // namespace
 
 struct orbx_matcher {
@@ -1670,6 +1711,31 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
     for (int i = 0; i < n; i++)
         if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
     *count = c;
+    return ORBX_OK;
+}
+
+orbx_status orbx_best_descriptor_batch(orbx_matcher* h, const uint8_t* descriptors, const int32_t* point_start,
+                                       int n_points, int32_t* best_index) {
+    if (!h || !point_start || !best_index || n_points < 0) return ORBX_BAD_ARG;
+    if (n_points == 0) return ORBX_OK;
+    if (point_start[0] != 0) return ORBX_BAD_ARG;
+    for (int p = 0; p < n_points; p++) {
+        if (point_start[p + 1] < point_start[p]) return ORBX_BAD_ARG;
+        if (point_start[p + 1] - point_start[p] > kBestMaxObs) return ORBX_CAPACITY;
+    }
+    const int total = point_start[n_points];
+    if (total > 0 && !descriptors) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_q.ensure(std::max((size_t)total * 32, (size_t)32)));
+    ORBX_TRY(h->d_ints.ensure((size_t)n_points + 1));
+    ORBX_TRY(h->d_idx.ensure(n_points));
+    if (total > 0) ORBX_HIP(hipMemcpyAsync(h->d_q.p, descriptors, (size_t)total * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_ints.p, point_start, sizeof(int32_t) * (n_points + 1), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_best_descriptor, dim3(n_points), dim3(64), 0, s, h->d_q.p, h->d_ints.p, n_points, h->d_idx.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(best_index, h->d_idx.p, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
     return ORBX_OK;
 }
 

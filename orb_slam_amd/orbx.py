@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -354,6 +354,14 @@ class Matcher:
                                                   C.c_float(nn_ratio), _p(out), C.byref(n)),
                "orbx_match_projection_points")
         return out[:n.value].copy()
+
+    def best_descriptor_batch(self, desc, point_start):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        ps = np.ascontiguousarray(point_start, np.int32)
+        best = np.zeros(max(len(ps) - 1, 1), np.int32)
+        _check(lib().orbx_best_descriptor_batch(self._h, _p(desc), _p(ps), len(ps) - 1, _p(best)),
+               "orbx_best_descriptor_batch")
+        return best[:len(ps) - 1].copy()
 
     def match_bow(self, kps, desc, ref_kps, ref_desc, ref_has_point, nodes, ref_nodes, low_threshold=50, nn_ratio=0.6,
                   check_orientation=True):

@@ -516,3 +516,19 @@ def test_bow_matcher_bit_exact(oracle, matcher, ex1000, test_images):
     bad = (nodes[0][::-1].copy(), nodes[1], nodes[2])
     with pytest.raises(orbx.OrbxError):
         matcher.match_bow(k0, d0, k1, d1, has, bad, ref_nodes)
+
+
+def test_best_descriptor_batch_bit_exact(oracle, matcher):
+    """MapPoint::computeBestDescriptor (map_point.cpp:109-166) for a batch of observation sets."""
+    rng = np.random.default_rng(71)
+    sizes = [0, 1, 2, 3, 4, 5, 8, 17, 63, 64, 65, 200] + rng.integers(1, 40, 300).tolist()
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = np.zeros((start[-1], 32), np.uint8)
+    for p, n in enumerate(sizes):
+        centre = rng.integers(0, 256, 32, dtype=np.uint8)
+        noise = (rng.uniform(size=(n, 256)) < rng.uniform(0.02, 0.3)).astype(np.uint8)
+        desc[start[p]:start[p + 1]] = centre ^ np.packbits(noise, axis=1)
+    got = matcher.best_descriptor_batch(desc, start)
+    want = oracle.best_descriptor(desc, start)
+    assert np.array_equal(got, want)
+    assert got[0] == -1 and got[1] == 0
