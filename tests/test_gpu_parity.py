@@ -532,3 +532,54 @@ def test_best_descriptor_batch_bit_exact(oracle, matcher):
     want = oracle.best_descriptor(desc, start)
     assert np.array_equal(got, want)
     assert got[0] == -1 and got[1] == 0
+
+
+def test_full_size_batches_are_consistent(oracle, ransac, test_images):
+    """The bench-sized batches (256 VGA frames; 1024 pairs x 200 iterations x 2000 correspondences): every copy of a
+    repeated unit gives the unit's result, and the distinct units equal the oracle."""
+    import torch
+    # extraction: 256 frames tiled from 4 distinct ones
+    distinct = [test_images[0], test_images[1], synth_image(91, 640, 480, 3), synth_image(92, 640, 480, 3)]
+    B, cap = 256, 1280
+    dev = torch.from_numpy(np.stack([distinct[f % 4] for f in range(B)])).cuda()
+    torch.cuda.synchronize()
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=B)
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), B, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    p = oracle.orb_params(nfeatures=1000)
+    for u in range(4):
+        ok_, od = oracle.compute(p, distinct[u], oracle.detect(p, distinct[u]))
+        for f in range(u, B, 4):
+            assert counts[f] == len(ok_)
+        f_all = np.arange(u, B, 4)
+        assert (kps[f_all, :len(ok_)] == ok_.astype(orbx.KP_DTYPE)[None]).all()
+        assert (desc[f_all, :len(ok_)] == od[None]).all()
+    ex.close()
+    # RANSAC: 1024 pairs tiled from 8 distinct ones
+    rng = np.random.default_rng(93)
+    P, n, it, D = 1024, 2000, 200, 8
+    data = [_two_view(rng, n, 600, planar=(i % 2 == 1)) for i in range(D)]
+    sets_d = [orbx.ransac_make_sets(n, it, 300 + i) for i in range(D)]
+    pts = np.ascontiguousarray(np.stack([data[i % D][0] for i in range(P)]))
+    ref = np.ascontiguousarray(np.stack([data[i % D][1] for i in range(P)]))
+    sets = np.stack([sets_d[i % D] for i in range(P)])
+    d_pts, d_ref = torch.from_numpy(pts).cuda(), torch.from_numpy(ref).cuda()
+    d_sets = torch.from_numpy(sets.astype(np.int64)).to(torch.int32).cuda()
+    d_F = torch.zeros((P, 9), dtype=torch.float32, device="cuda")
+    d_H = torch.zeros_like(d_F)
+    d_if = torch.zeros((P, n), dtype=torch.uint8, device="cuda")
+    d_ih = torch.zeros_like(d_if)
+    d_sc = torch.zeros((P, 2), dtype=torch.float32, device="cuda")
+    d_best = torch.zeros((P, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ransac.fh_batch(d_pts.data_ptr(), d_ref.data_ptr(), n, d_sets.data_ptr(), it, P, 1.0, d_F.data_ptr(),
+                    d_H.data_ptr(), d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_best.data_ptr())
+    torch.cuda.synchronize()
+    F, Hm, best, sc = d_F.cpu().numpy(), d_H.cpu().numpy(), d_best.cpu().numpy(), d_sc.cpu().numpy()
+    inl_f, inl_h = d_if.cpu().numpy(), d_ih.cpu().numpy()
+    for u in range(D):
+        o = oracle.ransac_fh(data[u][0], data[u][1], sets_d[u], 1.0)
+        idx = np.arange(u, P, D)
+        assert (best[idx] == o["best_it"][None]).all()
+        assert (F[idx] == o["F"].reshape(1, 9)).all() and (Hm[idx] == o["H"].reshape(1, 9)).all()
+        assert (inl_f[idx] == o["inliers_f"][None]).all() and (inl_h[idx] == o["inliers_h"][None]).all()
+        assert (sc[idx, 0] == np.float32(o["score_f"])).all() and (sc[idx, 1] == np.float32(o["score_h"])).all()
