@@ -50,7 +50,6 @@ struct orbx_extractor {
     DevBuf<CoefY> d_coefy;
     DevBuf<Tile> d_tiles;
     DevBuf<Strip> d_strips;
-    DevBuf<Coef> d_coefs;
     DevBuf<BriefPattern> d_pattern;
     UMax umax;
     BlurKernel blur_kernel;
@@ -263,7 +262,6 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
     ORBX_TRY(h->d_tiles.ensure(h->tiles.size()));
     ORBX_TRY(h->d_strips.ensure(h->strips.size()));
     ORBX_HIP(hipMemcpyAsync(h->d_strips.p, h->strips.data(), h->strips.size() * sizeof(Strip), hipMemcpyHostToDevice, h->stream));
-    ORBX_TRY(h->d_coefs.ensure(std::max<size_t>(h->coefs.size(), 1)));
     ORBX_TRY(h->d_coefx.ensure(std::max<size_t>(h->coefx.size(), 4)));
     ORBX_TRY(h->d_coefy.ensure(std::max<size_t>(h->coefy.size(), 1)));
     if (!h->coefx.empty()) {
@@ -271,8 +269,6 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
         ORBX_HIP(hipMemcpyAsync(h->d_coefy.p, h->coefy.data(), h->coefy.size() * sizeof(CoefY), hipMemcpyHostToDevice, h->stream));
     }
     ORBX_HIP(hipMemcpyAsync(h->d_tiles.p, h->tiles.data(), h->tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, h->stream));
-    if (!h->coefs.empty())
-        ORBX_HIP(hipMemcpyAsync(h->d_coefs.p, h->coefs.data(), h->coefs.size() * sizeof(Coef), hipMemcpyHostToDevice, h->stream));
     ORBX_HIP(hipStreamSynchronize(h->stream));
     h->cur_w = w;
     h->cur_h = hgt;
@@ -596,7 +592,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    h->d_tiles.release(); h->d_strips.release(); h->d_coefs.release(); h->d_coefx.release(); h->d_coefy.release(); h->d_pattern.release();
+    h->d_tiles.release(); h->d_strips.release(); h->d_coefx.release(); h->d_coefy.release(); h->d_pattern.release();
     h->d_in.release(); h->d_atlas.release(); h->d_score.release(); h->d_blur.release(); h->d_desc.release();
     h->d_mask.release(); h->d_steer.release(); h->d_cand.release(); h->d_packed.release();
     h->d_acc.release();
