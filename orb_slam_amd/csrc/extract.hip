@@ -52,7 +52,6 @@ struct orbx_extractor {
     DevBuf<Strip> d_strips;
     DevBuf<BriefPattern> d_pattern;
     UMax umax;
-    BlurKernel blur_kernel;
     BlurTaps blur_taps;
     float harris_scale_sq_sq = 0.f;
 
@@ -380,7 +379,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
     {
-        const int chunks = frames >= 64 ? 16 : 256;
+        const int chunks = frames >= 64 ? 32 : 256;
         hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
                            h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq,
                            chunks, frames);
@@ -556,6 +555,7 @@ orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_w
         const double sigma = 2.0;
         double scale2x = -0.5 / (sigma * sigma);
         float cf[7];
+        int k[7];
         double sum = 0;
         for (int i = 0; i < n; i++) {
             double x = i - (n - 1) * 0.5;
@@ -565,9 +565,8 @@ orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_w
         sum = 1. / sum;
         for (int i = 0; i < n; i++) {
             cf[i] = (float)(cf[i] * sum);
-            h->blur_kernel.k[i] = (int)lrintf(cf[i] * 256.f);
+            k[i] = (int)lrintf(cf[i] * 256.f);
         }
-        const int* k = h->blur_kernel.k;
         // the kernel packs the taps for v_dot4_u32_u8: they must be symmetric bytes
         if (k[0] != k[6] || k[1] != k[5] || k[2] != k[4] || k[3] > 255 || k[0] < 0) { orbx_extractor_destroy(h); return ORBX_UNSUPPORTED; }
         h->blur_taps.wa = (unsigned)k[0] | ((unsigned)k[1] << 8) | ((unsigned)k[2] << 16) | ((unsigned)k[3] << 24);

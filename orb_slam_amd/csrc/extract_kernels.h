@@ -259,16 +259,6 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
     }
 }
 
-// 9 contiguous set bits in a circular 16-bit mask.
-__device__ __forceinline__ bool has_arc9(unsigned m) {
-    m |= m << 16;
-    unsigned r = m & (m >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= m >> 8;
-    return r != 0;
-}
-
 // K3+K4a fused: FAST-9/16 score and 3x3 strict non-max suppression of one 64 x kTileH tile, never leaving LDS.
 //   phase 1  every pixel of the tile (plus a one-pixel ring for the suppression) takes the four-point compass test,
 //            four pixels per lane from whole staged dwords, evaluated on 64-bit lane masks with scalar logic; the
@@ -618,12 +608,6 @@ __global__ __launch_bounds__(256) void k_emit_finish(Geom g, int chunks, const i
         all = wave_scan_incl(all);
         if (lane == 63) totals[b] = all;
     }
-}
-
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
 }
 
 // cv::fastAtan2 (scalar atan_f32), degrees in [0, 360).
@@ -1010,8 +994,6 @@ __global__ void k_pack_cands(const Cand* __restrict__ cand, int cap, const int* 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) packed[offsets[b] + i] = cand[(size_t)b * cap + i];
 }
-
-struct BlurKernel { int k[7]; };
 
 // K7: cv::GaussianBlur(7x7, sigma 2) of every level as cv::ORB applies it (8-bit fixed-point separable filter,
 // taps round(g*256), rows then columns, (sum + 2^15) >> 16).  Dword-wise: a lane owns 4 adjacent atlas pixels of a
