@@ -11,8 +11,11 @@
 #pragma once
 #include <algorithm>
 
+#include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <orb_slam/geometry/utils.h>
@@ -175,19 +178,10 @@ public:
         std::vector<uint8_t> has(n_ref, 0);
         for (int i = 0; i < n_ref && i < (int)ref_map_points.size(); ++i)
             has[i] = ref_map_points[i] && !ref_map_points[i]->isBad();
-        auto flatten = [](const auto& fv, std::vector<uint32_t>& ids, std::vector<int32_t>& start,
-                          std::vector<int32_t>& items) {
-            start.push_back(0);
-            for (const auto& node : fv) {
-                ids.push_back((uint32_t)node.first);
-                for (auto i : node.second) items.push_back((int32_t)i);
-                start.push_back((int32_t)items.size());
-            }
-        };
         std::vector<uint32_t> ids, ref_ids;
         std::vector<int32_t> start, items, ref_start, ref_items;
-        flatten(frame->bowFeatures(), ids, start, items);
-        flatten(ref_frame->bowFeatures(), ref_ids, ref_start, ref_items);
+        flattenFeatureVector(frame->bowFeatures(), ids, start, items);
+        flattenFeatureVector(ref_frame->bowFeatures(), ref_ids, ref_start, ref_items);
         std::vector<cv::DMatch> out(std::max(n, 1));
         int count = 0;
         const int low_threshold = 50;  // orb_matcher.h:201
@@ -200,6 +194,193 @@ public:
                 reinterpret_cast<orbx_match*>(out.data()), &count),
             "ORBMatcher::matchByBowFeatures");
         matches.insert(matches.end(), out.begin(), out.begin() + count);
+    }
+
+    /**
+     * Map-point projection matcher (orb_matcher.cpp:763-778, 257-352).  With compute_track_info the track
+     * properties are refreshed through the frame's own isInCameraView(mp, props, 0.5) exactly as the reference does
+     * (:273-279); the search itself runs on the device.  The map point type provides resetTrackProperties(),
+     * setTrackProperties(), trackProperties() (in_view_, proj_xy_, pred_scale_level_, view_cosine_), isBad() and
+     * bestDescriptor().
+     */
+    template <typename FramePtrT, typename MapPointPtrT>
+    void matchByProjection(
+        const FramePtrT& frame,
+        const std::vector<MapPointPtrT>& points_3d,
+        std::vector<cv::DMatch>& matches,
+        const bool compute_track_info,
+        const float nn_ratio = 0.6,
+        const float radius = 1.0) const
+    {
+        const auto& key_points = frame->featuresUndist();
+        const cv::Mat& descriptors = frame->descriptorsUndist();
+        const int n = (int)key_points.size(), n_pts = (int)points_3d.size();
+        std::vector<uint8_t> in_view(std::max(n_pts, 1), 0);
+        std::vector<float> xy(2 * (size_t)std::max(n_pts, 1), 0.f), view_cos(std::max(n_pts, 1), 0.f);
+        std::vector<int32_t> pred(std::max(n_pts, 1), 0);
+        cv::Mat pt_desc(std::max(n_pts, 1), 32, CV_8U);
+        for (int i = 0; i < n_pts; ++i) {
+            const auto& mp = points_3d[i];
+            if (!mp) continue;
+            if (compute_track_info) {
+                typename std::decay<decltype(mp->trackProperties())>::type track_results;
+                mp->resetTrackProperties();
+                if (frame->isInCameraView(mp, track_results, 0.5))
+                    mp->setTrackProperties(track_results);
+            }
+            const auto& props = mp->trackProperties();
+            if (!props.in_view_ || mp->isBad()) continue;
+            in_view[i] = 1;
+            xy[2 * i] = props.proj_xy_.x;
+            xy[2 * i + 1] = props.proj_xy_.y;
+            pred[i] = props.pred_scale_level_;
+            view_cos[i] = props.view_cosine_;
+            std::memcpy(pt_desc.template ptr<uint8_t>(i), mp->bestDescriptor().data, 32);
+        }
+        orbx_grid g = gridOf(frame);
+        std::vector<cv::KeyPoint> kps(key_points);
+        std::vector<int32_t> cell_start((size_t)g.grid_cols * g.grid_rows + 1), cell_items(std::max(n, 1));
+        int kept = n;
+        orbx_compat::check(
+            orbx_assign_grid(&g, reinterpret_cast<orbx_keypoint*>(kps.data()), &kept, cell_start.data(), cell_items.data()),
+            "matchByProjection(grid)");
+        const auto& sf = frame->orbExtractor()->scaleFactors();
+        std::vector<cv::DMatch> out(std::max(n, 1));
+        int count = 0;
+        orbx_compat::check(
+            orbx_match_projection_points(
+                handle_.get(), &g, cell_start.data(), cell_items.data(),
+                reinterpret_cast<const orbx_keypoint*>(kps.data()), kept, descriptors.data, n_pts, in_view.data(),
+                xy.data(), pred.data(), view_cos.data(), pt_desc.data, sf.data(), (int)sf.size(), radius, nn_ratio,
+                reinterpret_cast<orbx_match*>(out.data()), &count),
+            "ORBMatcher::matchByProjection(points)");
+        matches.insert(matches.end(), out.begin(), out.begin() + count);
+    }
+
+    /**
+     * Epipolar matcher between two key frames (orb_matcher.cpp:780-791, 499-661).  The fundamental matrix comes
+     * from the key frame's own computeFundamentalMat(F, ref_key_frame), as in the reference (:508-510).
+     */
+    template <typename KeyFramePtrT>
+    void matchByEpipolarConstraint(
+        const KeyFramePtrT& key_frame,
+        const KeyFramePtrT& ref_key_frame,
+        std::vector<cv::DMatch>& matches,
+        const bool check_orientation = true) const
+    {
+        const auto map_points = key_frame->obsMapPoints();
+        const auto ref_map_points = ref_key_frame->obsMapPoints();
+        cv::Mat fundamental_mat;
+        key_frame->computeFundamentalMat(fundamental_mat, ref_key_frame);
+        const auto& frame = key_frame->frame();
+        const auto& ref_frame = ref_key_frame->frame();
+        const auto& key_points = frame->featuresUndist();
+        const auto& ref_key_points = ref_frame->featuresUndist();
+        const cv::Mat& descs = frame->descriptorsUndist();
+        const cv::Mat& ref_descs = ref_frame->descriptorsUndist();
+        const int n = (int)key_points.size(), n_ref = (int)ref_key_points.size();
+        std::vector<uint8_t> has(std::max(n, 1), 0), ref_has(std::max(n_ref, 1), 0);
+        for (int i = 0; i < n && i < (int)map_points.size(); ++i) has[i] = map_points[i] ? 1 : 0;
+        for (int i = 0; i < n_ref && i < (int)ref_map_points.size(); ++i) ref_has[i] = ref_map_points[i] ? 1 : 0;
+        std::vector<uint32_t> ids, ref_ids;
+        std::vector<int32_t> start, items, ref_start, ref_items;
+        flattenFeatureVector(frame->bowFeatures(), ids, start, items);
+        flattenFeatureVector(ref_frame->bowFeatures(), ref_ids, ref_start, ref_items);
+        float f9[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) f9[3 * r + c] = fundamental_mat.template at<float>(r, c);
+        const auto& sigmas = ref_frame->orbExtractor()->scaleSigmas();
+        std::vector<cv::DMatch> out(std::max(n, 1));
+        int count = 0;
+        const int low_threshold = 50;  // orb_matcher.h:201
+        orbx_compat::check(
+            orbx_match_epipolar(
+                handle_.get(), reinterpret_cast<const orbx_keypoint*>(key_points.data()), n, descs.data,
+                reinterpret_cast<const orbx_keypoint*>(ref_key_points.data()), n_ref, ref_descs.data, has.data(),
+                ref_has.data(), f9, sigmas.data(), (int)sigmas.size(), ids.data(), start.data(), items.data(),
+                (int)ids.size(), ref_ids.data(), ref_start.data(), ref_items.data(), (int)ref_ids.size(),
+                low_threshold, check_orientation ? 1 : 0, reinterpret_cast<orbx_match*>(out.data()), &count),
+            "ORBMatcher::matchByEpipolarConstraint");
+        matches.insert(matches.end(), out.begin(), out.begin() + count);
+    }
+
+    /**
+     * ORBMatcher::fuse (orb_matcher.cpp:793-888).  The per-point tests that read the map (:808-814) and the map
+     * bookkeeping (:869-884) run here on the host through the caller's own types, in the reference's order; the
+     * window search and descriptor comparison (:818-867) run on the device for all points at once.  The search of
+     * a point depends on the map only through isBad()/isObservedInKeyFrame(), so those two are evaluated again at
+     * the point's turn in the bookkeeping loop: the result equals the reference's sequential loop, duplicates in
+     * points_3d included.
+     */
+    template <typename KeyFramePtrT, typename MapPointPtrT>
+    int fuse(
+        const KeyFramePtrT key_frame,
+        const std::vector<MapPointPtrT>& points_3d,
+        const float radius_multiplier = 3.0) const
+    {
+        const auto map_points = key_frame->obsMapPoints();
+        const auto& frame = key_frame->frame();
+        const auto& key_points = frame->featuresUndist();
+        const cv::Mat& descriptors = frame->descriptorsUndist();
+        const int n = (int)key_points.size(), n_pts = (int)points_3d.size();
+        key_frame->updateWorldInCamLocal();
+        std::vector<uint8_t> in_view(std::max(n_pts, 1), 0);
+        std::vector<float> xy(2 * (size_t)std::max(n_pts, 1), 0.f);
+        std::vector<int32_t> pred(std::max(n_pts, 1), 0);
+        cv::Mat pt_desc(std::max(n_pts, 1), 32, CV_8U);
+        for (int i = 0; i < n_pts; ++i) {
+            const auto& mp = points_3d[i];
+            if (!mp || mp->isBad() || mp->isObservedInKeyFrame(key_frame)) continue;
+            typename std::decay<decltype(mp->trackProperties())>::type props;
+            if (!key_frame->isInCameraViewLocal(mp, props, 0.5)) continue;
+            in_view[i] = 1;
+            xy[2 * i] = props.proj_xy_.x;
+            xy[2 * i + 1] = props.proj_xy_.y;
+            pred[i] = props.pred_scale_level_;
+            std::memcpy(pt_desc.template ptr<uint8_t>(i), mp->bestDescriptor().data, 32);
+        }
+        orbx_grid g = gridOf(frame);
+        std::vector<cv::KeyPoint> kps(key_points);
+        std::vector<int32_t> cell_start((size_t)g.grid_cols * g.grid_rows + 1), cell_items(std::max(n, 1));
+        int kept = n;
+        orbx_compat::check(
+            orbx_assign_grid(&g, reinterpret_cast<orbx_keypoint*>(kps.data()), &kept, cell_start.data(), cell_items.data()),
+            "fuse(grid)");
+        if (kept != n)
+            throw std::runtime_error("ORBMatcher::fuse: key frame features outside the image bounds");
+        const auto& sf = frame->orbExtractor()->scaleFactors();
+        const auto& inv_sigmas = frame->orbExtractor()->invScaleSigmas();
+        std::vector<int32_t> best_idx(std::max(n_pts, 1), -1), best_dist(std::max(n_pts, 1), 256);
+        orbx_compat::check(
+            orbx_fuse_search(
+                handle_.get(), &g, cell_start.data(), cell_items.data(),
+                reinterpret_cast<const orbx_keypoint*>(kps.data()), kept, descriptors.data, n_pts, in_view.data(),
+                xy.data(), pred.data(), pt_desc.data, sf.data(), inv_sigmas.data(), (int)sf.size(), radius_multiplier,
+                best_idx.data(), best_dist.data()),
+            "ORBMatcher::fuse");
+        const int low_threshold = 50;  // orb_matcher.h:201
+        int n_fused = 0;
+        for (int i = 0; i < n_pts; ++i) {
+            if (!in_view[i] || best_idx[i] < 0) continue;
+            // the reference skips a point with an empty window before the threshold test (:824-832) and counts
+            // every point whose best distance passes it (:870-884)
+            if (best_dist[i] > low_threshold) continue;
+            const auto& mp = points_3d[i];
+            if (mp->isBad() || mp->isObservedInKeyFrame(key_frame)) continue;
+            const int matched_id = best_idx[i];
+            auto mp_kf = map_points[matched_id];
+            if (mp_kf) {
+                if (!mp_kf->isBad()) {
+                    if (mp_kf->nObservations() > mp->nObservations()) mp->replace(mp_kf);
+                    else mp_kf->replace(mp);
+                }
+            } else {
+                mp->addObservation(key_frame, matched_id);
+                key_frame->setMapPointAt(mp, matched_id);
+            }
+            n_fused++;
+        }
+        return n_fused;
     }
 
     /** ORBMatcher::filterMatches (orb_matcher.cpp:890-924). */
@@ -215,6 +396,18 @@ public:
     }
 
 private:
+    //! DBoW2::FeatureVector-like ordered map (node id -> feature indices) as the CSR arrays of the C ABI
+    template <typename FeatureVectorT>
+    static void flattenFeatureVector(const FeatureVectorT& fv, std::vector<uint32_t>& ids,
+                                     std::vector<int32_t>& start, std::vector<int32_t>& items) {
+        start.push_back(0);
+        for (const auto& node : fv) {
+            ids.push_back((uint32_t)node.first);
+            for (auto i : node.second) items.push_back((int32_t)i);
+            start.push_back((int32_t)items.size());
+        }
+    }
+
     template <typename FramePtrT>
     static orbx_grid gridOf(const FramePtrT& frame) {
         const auto& cam = frame->camera();

@@ -212,6 +212,34 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
                            int low_threshold, float nn_ratio, int check_orientation, orbx_match* matches,
                            int* count);
 
+/* Replaces EpipolarConstraintWithBowMatcher::match (orb_matcher.cpp:520-661) with the fundamental matrix
+   (KeyFrame::computeFundamentalMat, row-major 3x3) supplied by the caller; feature vectors as in orbx_match_bow.
+   has_point[i] / ref_has_point[i] = feature i of the (reference) key frame already has a map point.  scale_sigmas =
+   ORBExtractor::scaleSigmas() of the reference frame.  The reference's arithmetic is kept as written, including
+   its reading of row idx of BOTH descriptor matrices (:573) and of matched[ref_idx] (:565); where those reads
+   would leave the arrays (a feature index of a common node >= n_ref, a reference index >= n) ORBX_BAD_ARG is
+   returned.  low_threshold / check_orientation: orb_matcher.h (50, true). */
+orbx_status orbx_match_epipolar(orbx_matcher* h, const orbx_keypoint* keypoints, int n, const uint8_t* descriptors,
+                                const orbx_keypoint* ref_keypoints, int n_ref, const uint8_t* ref_descriptors,
+                                const uint8_t* has_point, const uint8_t* ref_has_point, const float* fundamental,
+                                const float* scale_sigmas, int n_levels, const uint32_t* node_ids,
+                                const int32_t* node_start, const int32_t* node_items, int n_nodes,
+                                const uint32_t* ref_node_ids, const int32_t* ref_node_start,
+                                const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
+                                int check_orientation, orbx_match* matches, int* count);
+
+/* Replaces the candidate search of ORBMatcher::fuse (orb_matcher.cpp:806-867) for the points that passed the
+   caller's own tests (:808-814: not bad, not yet observed in the key frame, KeyFrame::isInCameraViewLocal, whose
+   projection and predicted level arrive in proj_xy / pred_level).  best_index[p] = the key frame's feature with the
+   smallest descriptor distance in the window (-1: none), best_distance[p] that distance (256: none); the caller
+   applies best_distance <= low_threshold and the map bookkeeping (:869-884). */
+orbx_status orbx_fuse_search(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start, const int32_t* cell_items,
+                             const orbx_keypoint* keypoints, int n, const uint8_t* descriptors, int n_points,
+                             const uint8_t* in_view, const float* proj_xy, const int32_t* pred_level,
+                             const uint8_t* point_descriptors, const float* scale_factors,
+                             const float* inv_scale_sigmas, int n_levels, float radius_multiplier,
+                             int32_t* best_index, int32_t* best_distance);
+
 /* Replaces the arithmetic of MapPoint::computeBestDescriptor (src/map_point.cpp:109-166) for a batch of map points:
    the observed descriptors of point p are rows point_start[p] .. point_start[p + 1] of `descriptors` (32 bytes
    each, at most 1024 per point); best_index[p] = the row inside the set with the least median Hamming distance to

@@ -335,6 +335,119 @@ int orc_match_bow(const orc_keypoint* kps, int n, const uint8_t* desc, const orc
     return create_matches(matched, feature_dists, out);
 }
 
+/* EpipolarConstraintWithBowMatcher::match + check_epipolar_dist, orb_matcher.cpp:520-661, as written:
+   - the descriptor distance of the inner loop is taken between row `idx` of BOTH descriptor matrices (:573), so it
+     does not depend on the candidate, and with `dist > min_feature_dist` (:576) the LAST candidate of the node that
+     passes the epipolar test is the one kept;
+   - the "already matched" test reads matched[ref_idx] (:565), an array indexed by the features of `frame`.
+   Both reads need idx < n_ref and ref_idx < n for every index of a common node; -1 is returned otherwise.
+   has_mp[i] / ref_has_mp[i] = the (ref) key frame's feature i already has a map point (any, bad or not). */
+int orc_match_epipolar(const orc_keypoint* kps, int n, const uint8_t* desc, const orc_keypoint* ref_kps, int n_ref,
+                       const uint8_t* ref_desc, const uint8_t* has_mp, const uint8_t* ref_has_mp, const float* F9,
+                       const float* scale_sigmas, const uint32_t* node_ids, const int32_t* node_start,
+                       const int32_t* node_items, int n_nodes, const uint32_t* ref_node_ids,
+                       const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes,
+                       int low_threshold, int check_orientation, orc_match* out) {
+    const int hist_length = 30;
+    std::vector<int> matched(n, -1), feature_dists(n, -1);
+    std::vector<std::vector<int>> rot_hist(hist_length);
+    const float factor = 1.0f / hist_length;
+    auto epipolar_ok = [&](const orc_keypoint& kp1, const orc_keypoint& kp2) { /* :628-661 */
+        const float a = kp1.x * F9[0] + kp1.y * F9[3] + F9[6];
+        const float b = kp1.x * F9[1] + kp1.y * F9[4] + F9[7];
+        const float c = kp1.x * F9[2] + kp1.y * F9[5] + F9[8];
+        const float num = a * kp2.x + b * kp2.y + c;
+        const float den = a * a + b * b;
+        if (den == 0) return false;
+        const float dsqr = num * num / den;
+        return dsqr < 3.84 * scale_sigmas[kp2.octave];
+    };
+    int f = 0, rf = 0;
+    while (rf < n_ref_nodes && f < n_nodes) {
+        if (ref_node_ids[rf] == node_ids[f]) {
+            for (int b = node_start[f]; b < node_start[f + 1]; ++b) {
+                const int idx = node_items[b];
+                if (has_mp[idx]) continue;
+                if (idx >= n_ref) return -1;
+                int min_feature_dist = low_threshold, matched_id = -1;
+                for (int a = ref_node_start[rf]; a < ref_node_start[rf + 1]; ++a) {
+                    const int ref_idx = ref_node_items[a];
+                    if (ref_idx >= n) return -1;
+                    if (matched[ref_idx] > 0 || ref_has_mp[ref_idx]) continue;
+                    const int dist = orc_descriptor_distance(ref_desc + (size_t)idx * 32, desc + (size_t)idx * 32);
+                    if (dist > low_threshold || dist > min_feature_dist) continue;
+                    if (epipolar_ok(kps[idx], ref_kps[ref_idx])) {
+                        matched_id = ref_idx;
+                        min_feature_dist = dist;
+                    }
+                }
+                if (matched_id >= 0) {
+                    matched[idx] = matched_id;
+                    feature_dists[idx] = min_feature_dist;
+                    if (check_orientation) {
+                        float rot_diff = kps[idx].angle - ref_kps[matched_id].angle;
+                        if (rot_diff < 0.0) rot_diff += 360.0f;
+                        int bin = round(rot_diff * factor);
+                        if (bin == hist_length) bin = 0;
+                        rot_hist[bin].push_back(idx);
+                    }
+                }
+            }
+            f++;
+            rf++;
+        } else if (ref_node_ids[rf] < node_ids[f]) {
+            while (rf < n_ref_nodes && ref_node_ids[rf] < node_ids[f]) rf++; /* lower_bound */
+        } else {
+            while (f < n_nodes && node_ids[f] < ref_node_ids[rf]) f++;
+        }
+    }
+    if (check_orientation) {
+        int sizes[30], i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < hist_length; i++) sizes[i] = (int)rot_hist[i].size();
+        orc_three_maxima(sizes, hist_length, &i1, &i2, &i3);
+        for (int i = 0; i < hist_length; i++)
+            if (i != i1 && i != i2 && i != i3)
+                for (int v : rot_hist[i]) matched[v] = 0;
+    }
+    return create_matches(matched, feature_dists, out);
+}
+
+/* The search of ORBMatcher::fuse, orb_matcher.cpp:806-867, for points whose frustum test (:808-814) the caller has
+   done: per point the feature of the key frame with the smallest descriptor distance (`<`, first in scan order)
+   inside the window of radius radius_multiplier * scale_factor[level] on levels [level-1, level] whose squared
+   reprojection error passes e2 * inv_sigma2[octave] <= 5.99.  `matched` of the reference is never written inside
+   fuse, so the points are independent.  best_idx = -1 / best_dist = 256 when nothing qualifies; the caller applies
+   `best_dist <= low_threshold` and the map bookkeeping (:869-884). */
+void orc_fuse_search(const orc_grid_params* g, const int32_t* cell_start, const int32_t* cell_items,
+                     const orc_keypoint* kps, const uint8_t* desc, int n_pts, const uint8_t* in_view,
+                     const float* proj_xy, const int32_t* pred_level, const uint8_t* pt_desc,
+                     const float* scale_factors, const float* inv_scale_sigmas, float radius_multiplier,
+                     int32_t* best_idx, int32_t* best_dist) {
+    for (int p = 0; p < n_pts; ++p) {
+        best_idx[p] = -1;
+        best_dist[p] = 256;
+        if (!in_view[p]) continue;
+        const int level = pred_level[p];
+        const float px = proj_xy[2 * p], py = proj_xy[2 * p + 1];
+        const float radius_scaled = radius_multiplier * scale_factors[level];
+        std::vector<int> close;
+        if (!features_around(g, cell_start, cell_items, kps, px, py, radius_scaled, level - 1, level, false, close))
+            continue;
+        int min_feature_dist = 256, matched_id = -1;
+        for (int idx : close) {
+            const orc_keypoint& k = kps[idx];
+            if (k.octave < level - 1 || k.octave > level) continue;
+            const float ex = px - k.x, ey = py - k.y;
+            const float e_sqrd = ex * ex + ey * ey;
+            if (e_sqrd * inv_scale_sigmas[k.octave] > 5.99) continue;
+            const int dist = orc_descriptor_distance(pt_desc + (size_t)p * 32, desc + (size_t)idx * 32);
+            if (dist < min_feature_dist) { min_feature_dist = dist; matched_id = idx; }
+        }
+        best_idx[p] = matched_id;
+        best_dist[p] = min_feature_dist;
+    }
+}
+
 /* MapPoint::computeBestDescriptor, map_point.cpp:109-166, for n_points descriptor sets laid out back to back
    (point p owns rows point_start[p] .. point_start[p+1]).  best[p] = row inside the set, -1 for an empty set. */
 void orc_best_descriptor(const uint8_t* desc, const int32_t* point_start, int n_points, int32_t* best) {

@@ -128,6 +128,22 @@ int  orc_match_bow(const orc_keypoint* kps, int n, const uint8_t* desc, const or
                    const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
                    float nn_ratio, int check_orientation, orc_match* out);
 
+/* Epipolar matcher, orb_matcher.cpp:520-661 (quirks kept, see the definition).  Returns -1 when a node index is
+   out of range for the arrays the reference indexes with it. */
+int  orc_match_epipolar(const orc_keypoint* kps, int n, const uint8_t* desc, const orc_keypoint* ref_kps, int n_ref,
+                        const uint8_t* ref_desc, const uint8_t* has_mp, const uint8_t* ref_has_mp, const float* F9,
+                        const float* scale_sigmas, const uint32_t* node_ids, const int32_t* node_start,
+                        const int32_t* node_items, int n_nodes, const uint32_t* ref_node_ids,
+                        const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes,
+                        int low_threshold, int check_orientation, orc_match* out);
+
+/* Candidate search of ORBMatcher::fuse, orb_matcher.cpp:806-867. */
+void orc_fuse_search(const orc_grid_params* g, const int32_t* cell_start, const int32_t* cell_items,
+                     const orc_keypoint* kps, const uint8_t* desc, int n_pts, const uint8_t* in_view,
+                     const float* proj_xy, const int32_t* pred_level, const uint8_t* pt_desc,
+                     const float* scale_factors, const float* inv_scale_sigmas, float radius_multiplier,
+                     int32_t* best_idx, int32_t* best_dist);
+
 /* MapPoint::computeBestDescriptor (map_point.cpp:109-166) over descriptor sets laid out back to back. */
 void orc_best_descriptor(const uint8_t* desc, const int32_t* point_start, int n_points, int32_t* best);
 

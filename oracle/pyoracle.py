@@ -302,6 +302,48 @@ def match_bow(kps, desc, ref_kps, ref_desc, ref_has_mp, nodes, ref_nodes, low_th
     return out[:n].copy()
 
 
+def match_epipolar(kps, desc, ref_kps, ref_desc, has_mp, ref_has_mp, F, scale_sigmas, nodes, ref_nodes,
+                   low_threshold, check_orientation):
+    """Epipolar matcher; nodes as in match_bow.  Returns None when the reference would index out of range."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+    has_mp = np.ascontiguousarray(has_mp, np.uint8)
+    ref_has_mp = np.ascontiguousarray(ref_has_mp, np.uint8)
+    F = np.ascontiguousarray(F, np.float32).reshape(9)
+    sig = np.ascontiguousarray(scale_sigmas, np.float32)
+    ni, ns, nit = (np.ascontiguousarray(nodes[0], np.uint32), np.ascontiguousarray(nodes[1], np.int32),
+                   np.ascontiguousarray(nodes[2], np.int32))
+    ri, rs, rit = (np.ascontiguousarray(ref_nodes[0], np.uint32), np.ascontiguousarray(ref_nodes[1], np.int32),
+                   np.ascontiguousarray(ref_nodes[2], np.int32))
+    out = np.zeros(max(len(kps), 1), MATCH_DTYPE)
+    n = lib().orc_match_epipolar(_p(kps), len(kps), _p(desc), _p(ref_kps), len(ref_kps), _p(ref_desc), _p(has_mp),
+                                 _p(ref_has_mp), _p(F), _p(sig), _p(ni), _p(ns), _p(nit), len(ni), _p(ri), _p(rs),
+                                 _p(rit), len(ri), int(low_threshold), int(bool(check_orientation)), _p(out))
+    if n < 0:
+        return None
+    return out[:n].copy()
+
+
+def fuse_search(g, start, items, kps, desc, in_view, proj_xy, pred_level, pt_desc, scale_factors, inv_scale_sigmas,
+                radius_multiplier):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    in_view = np.ascontiguousarray(in_view, np.uint8)
+    proj_xy = np.ascontiguousarray(proj_xy, np.float32)
+    pred_level = np.ascontiguousarray(pred_level, np.int32)
+    pt_desc = np.ascontiguousarray(pt_desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    inv = np.ascontiguousarray(inv_scale_sigmas, np.float32)
+    best_idx = np.zeros(max(len(in_view), 1), np.int32)
+    best_dist = np.zeros(max(len(in_view), 1), np.int32)
+    lib().orc_fuse_search(C.byref(g), _p(start), _p(items), _p(kps), _p(desc), len(in_view), _p(in_view),
+                          _p(proj_xy), _p(pred_level), _p(pt_desc), _p(sf), _p(inv), C.c_float(radius_multiplier),
+                          _p(best_idx), _p(best_dist))
+    return best_idx[:len(in_view)].copy(), best_dist[:len(in_view)].copy()
+
+
 def best_descriptor(desc, point_start):
     desc = np.ascontiguousarray(desc, np.uint8)
     ps = np.ascontiguousarray(point_start, np.int32)

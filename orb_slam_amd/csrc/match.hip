@@ -1238,6 +1238,244 @@ __global__ __launch_bounds__(64) void k_best_descriptor(const uint8_t* __restric
     if (lane == 0) best[p] = best_idx;
 }
 
+// ---- EpipolarConstraintWithBowMatcher::match (orb_matcher.cpp:520-661) -------------------------------------------
+// One wavefront walks the common vocabulary nodes in order.  As the reference is written, the descriptor distance of
+// its inner loop is taken between row idx of BOTH descriptor matrices (:573), so it is a per-feature constant d0
+// (computed for all features in the prologue), and the candidate kept is the LAST one of the node's reference list
+// that is still free (matched[ref_idx] <= 0, an array indexed by the frame's own features, :565), has no map point and
+// passes the point-to-epipolar-line test (:628-661).  Per node the lanes hold up to 64 reference candidates in
+// registers and the node's features are staged in LDS, so the sequential walk over the features touches LDS only.
+struct EpiArgs {
+    const orbx_keypoint* kps;
+    int n;
+    const uint8_t* desc;
+    const orbx_keypoint* ref_kps;
+    int n_ref;
+    const uint8_t* ref_desc;
+    const uint8_t* has_mp;
+    const uint8_t* ref_has_mp;
+    float F[9];
+    const float* scale_sigmas;
+    int n_levels;
+    const int32_t* jobs;       // [n_jobs][4]: first feature, number of features, first candidate, number of candidates
+    int n_jobs;
+    const int32_t* items;      // the frame's feature vector, node after node
+    const int32_t* ref_items;  // the reference frame's
+    int low_threshold;
+    int check_orientation;
+    int32_t* matched;          // out [n]
+    int32_t* dists;            // out [n]
+    int32_t* pushes;           // scratch [2 * n]
+};
+
+__global__ __launch_bounds__(64) void k_epipolar_match(EpiArgs A) {
+    extern __shared__ int32_t s_mem[];
+    int32_t* s_matched = s_mem;                            // [n]
+    unsigned short* s_d0 = (unsigned short*)(s_mem + A.n);  // [n]: d0, or 0xffff when the feature cannot match
+    __shared__ float s_fx[64], s_fy[64];
+    __shared__ int32_t s_fid[64];
+    __shared__ int32_t s_hist[30];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < A.n; i += 64) {
+        s_matched[i] = -1;
+        A.dists[i] = -1;
+        unsigned short d0 = 0xffffu;
+        if (!A.has_mp[i] && i < A.n_ref) {
+            const int d = hamming32(A.ref_desc + (size_t)i * 32, A.desc + (size_t)i * 32);
+            if (d <= A.low_threshold) d0 = (unsigned short)d;
+        }
+        s_d0[i] = d0;
+    }
+    if (lane < 30) s_hist[lane] = 0;
+    __syncthreads();
+    int n_push = 0;
+    for (int job = 0; job < A.n_jobs; job++) {
+        const int f_start = A.jobs[4 * job], f_len = A.jobs[4 * job + 1];
+        const int rf_start = A.jobs[4 * job + 2], rf_len = A.jobs[4 * job + 3];
+        if (f_len <= 0 || rf_len <= 0) continue;
+        const int n_rchunks = (rf_len + 63) >> 6;
+        int r = 0;
+        float rx = 0.f, ry = 0.f;
+        double thr = 0.0;
+        bool rok = false;
+        auto load_chunk = [&](int rc) {
+            const int c = rc * 64 + lane;
+            rok = false;
+            r = 0;
+            if (c < rf_len) {
+                r = A.ref_items[rf_start + c];
+                const orbx_keypoint k = A.ref_kps[r];
+                rx = k.x;
+                ry = k.y;
+                rok = !A.ref_has_mp[r] && k.octave >= 0 && k.octave < A.n_levels;
+                if (rok) thr = 3.84 * A.scale_sigmas[k.octave];
+            }
+        };
+        if (n_rchunks == 1) load_chunk(0);
+        for (int fb = 0; fb < f_len; fb += 64) {
+            wave_lds_fence();
+            if (fb + lane < f_len) {
+                const int idx = A.items[f_start + fb + lane];
+                s_fid[lane] = idx;
+                s_fx[lane] = A.kps[idx].x;
+                s_fy[lane] = A.kps[idx].y;
+            }
+            wave_lds_fence();
+            const int cnt = min(64, f_len - fb);
+            for (int j = 0; j < cnt; j++) {
+                const int idx = s_fid[j];
+                const int d0 = s_d0[idx];
+                if (d0 == 0xffff) continue;
+                const float fx = s_fx[j], fy = s_fy[j];
+                const float a = fx * A.F[0] + fy * A.F[3] + A.F[6];
+                const float b = fx * A.F[1] + fy * A.F[4] + A.F[7];
+                const float c = fx * A.F[2] + fy * A.F[5] + A.F[8];
+                const float den = a * a + b * b;
+                int found = -1;
+                for (int rc = n_rchunks - 1; rc >= 0; rc--) {
+                    if (n_rchunks > 1) load_chunk(rc);
+                    bool pass = false;
+                    if (rok && !(s_matched[r] > 0) && den != 0) {
+                        const float num = a * rx + b * ry + c;
+                        const float dsqr = num * num / den;
+                        pass = (double)dsqr < thr;
+                    }
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal) {
+                        found = __shfl(r, 63 - __clzll((long long)bal));
+                        break;
+                    }
+                }
+                if (found >= 0) {
+                    if (lane == 0) {
+                        s_matched[idx] = found;
+                        A.dists[idx] = d0;
+                        if (A.check_orientation) {
+                            A.pushes[2 * n_push] = idx;
+                            A.pushes[2 * n_push + 1] = found;
+                        }
+                    }
+                    n_push++;
+                    wave_lds_fence();
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (A.check_orientation) {
+        __threadfence_block();
+        const float factor = 1.0f / 30;
+        for (int i = lane; i < n_push; i += 64) {
+            float rot = A.kps[A.pushes[2 * i]].angle - A.ref_kps[A.pushes[2 * i + 1]].angle;  // :595-597
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == 30) bin = 0;
+            if (bin < 0 || bin >= 30) bin = -1;
+            else atomicAdd(&s_hist[bin], 1);
+            A.pushes[2 * i + 1] = bin;
+        }
+        __syncthreads();
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < 30; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = lane; i < n_push; i += 64) {
+            const int bin = A.pushes[2 * i + 1];
+            if (bin >= 0 && bin != ind1 && bin != ind2 && bin != ind3) s_matched[A.pushes[2 * i]] = 0;
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < A.n; i += 64) A.matched[i] = s_matched[i];
+}
+
+// ---- candidate search of ORBMatcher::fuse (orb_matcher.cpp:806-867) ----------------------------------------------
+// `matched` is never written inside fuse, so the map points are independent: 16 lanes per point scan the search
+// window (radius_multiplier * scale factor of the predicted level, levels [level-1, level]) in the reference's cell
+// order, drop features whose squared reprojection error fails e2 * inv_sigma2[octave] <= 5.99 and keep the smallest
+// descriptor distance, first in scan order on ties (`<`, :862).
+struct FuseArgs {
+    orbx_grid g;
+    const int32_t* cell_start;
+    const int32_t* cell_items;
+    const orbx_keypoint* kps;
+    const uint8_t* desc;
+    int n_pts;
+    const uint8_t* in_view;
+    const float* proj_xy;
+    const int32_t* pred_level;
+    const uint8_t* pt_desc;
+    const float* scale_factors;
+    const float* inv_scale_sigmas;
+    int n_levels;
+    float radius_multiplier;
+    int32_t* best_idx;
+    int32_t* best_dist;
+};
+
+__global__ __launch_bounds__(256) void k_fuse_search(FuseArgs A) {
+    const int lane = threadIdx.x & 15;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= A.n_pts) return;
+    const orbx_grid& g = A.g;
+    unsigned long long best = ~0ull;  // distance << 40 | scan position (cell << 14 | item)
+    int best_id = -1;
+    const int level = A.pred_level[p];
+    if (A.in_view[p] && level >= 0 && level < A.n_levels) {
+        Window W;
+        W.px = A.proj_xy[2 * p];
+        W.py = A.proj_xy[2 * p + 1];
+        W.min_only = false;
+        W.radius_scaled = A.radius_multiplier * A.scale_factors[level];
+        W.min_level = level - 1;
+        W.max_level = level;
+        W.left = max(0, (int)floorf(W.px - g.min_x - W.radius_scaled) / g.grid_size_x);
+        const int right = min(g.grid_cols - 1, (int)ceilf(W.px - g.min_x + W.radius_scaled) / g.grid_size_x);
+        W.up = max(0, (int)floorf(W.py - g.min_y - W.radius_scaled) / g.grid_size_y);
+        const int down = min(g.grid_rows - 1, (int)ceilf(W.py - g.min_y + W.radius_scaled) / g.grid_size_y);
+        if (W.left < g.grid_cols && right >= 0 && W.up < g.grid_rows && down >= 0) {
+            W.ncy = down - W.up + 1;
+            W.ncells = (right - W.left + 1) * W.ncy;
+            const uint8_t* pd = A.pt_desc + (size_t)p * 32;
+            for (int c = lane; c < W.ncells; c += 16) {
+                const int cxi = W.left + c / W.ncy, cyi = W.up + c % W.ncy;
+                const int cell = cxi * g.grid_rows + cyi;
+                const int i0 = A.cell_start[cell], i1 = A.cell_start[cell + 1];
+                for (int i = i0; i < i1; i++) {
+                    const int idx = A.cell_items[i];
+                    const orbx_keypoint k = A.kps[idx];
+                    if (k.octave < 0 || !in_window(k, W, cxi, cyi)) continue;
+                    const float ex = W.px - k.x, ey = W.py - k.y;
+                    const float e_sqrd = ex * ex + ey * ey;
+                    if ((double)(e_sqrd * A.inv_scale_sigmas[k.octave]) > 5.99) continue;
+                    const unsigned long long d = (unsigned)hamming32(pd, A.desc + (size_t)idx * 32);
+                    const unsigned long long key = (d << 40) | ((unsigned long long)c << 14) | (unsigned)min(i - i0, 16383);
+                    if (key < best) { best = key; best_id = idx; }
+                }
+            }
+        }
+    }
+    unsigned long long w = best;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(w, o, 16);
+        w = other < w ? other : w;
+    }
+    // keys are unique per feature (scan positions differ), so exactly one lane owns the minimum
+    if (w != ~0ull && best == w) {
+        A.best_idx[p] = best_id;
+        A.best_dist[p] = (int)(w >> 40);
+    } else if (w == ~0ull && lane == 0) {
+        A.best_idx[p] = -1;
+        A.best_dist[p] = 256;
+    }
+}
+
 }  // namespace
 
 struct orbx_matcher {
@@ -1711,6 +1949,198 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
     for (int i = 0; i < n; i++)
         if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
     *count = c;
+    return ORBX_OK;
+}
+
+orbx_status orbx_match_epipolar(orbx_matcher* h, const orbx_keypoint* keypoints, int n, const uint8_t* descriptors,
+                                const orbx_keypoint* ref_keypoints, int n_ref, const uint8_t* ref_descriptors,
+                                const uint8_t* has_point, const uint8_t* ref_has_point, const float* fundamental,
+                                const float* scale_sigmas, int n_levels, const uint32_t* node_ids,
+                                const int32_t* node_start, const int32_t* node_items, int n_nodes,
+                                const uint32_t* ref_node_ids, const int32_t* ref_node_start,
+                                const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
+                                int check_orientation, orbx_match* matches, int* count) {
+    if (!h || !count || n < 0 || n_ref < 0 || n_nodes < 0 || n_ref_nodes < 0) return ORBX_BAD_ARG;
+    *count = 0;
+    if (n == 0 || n_ref == 0 || n_nodes == 0 || n_ref_nodes == 0) return ORBX_OK;
+    if (!keypoints || !descriptors || !ref_keypoints || !ref_descriptors || !has_point || !ref_has_point ||
+        !fundamental || !scale_sigmas || n_levels <= 0 || !node_ids || !node_start || !node_items || !ref_node_ids ||
+        !ref_node_start || !ref_node_items || !matches)
+        return ORBX_BAD_ARG;
+    if (n > kMaxFeatures) return ORBX_CAPACITY;
+    auto valid = [](const uint32_t* ids, const int32_t* start, const int32_t* items, int nn, int limit) {
+        if (start[0] != 0) return false;
+        for (int i = 0; i < nn; i++) {
+            if (start[i + 1] < start[i]) return false;
+            if (i > 0 && !(ids[i - 1] < ids[i])) return false;
+        }
+        for (int i = 0; i < start[nn]; i++)
+            if (items[i] < 0 || items[i] >= limit) return false;
+        return true;
+    };
+    if (!valid(node_ids, node_start, node_items, n_nodes, n) ||
+        !valid(ref_node_ids, ref_node_start, ref_node_items, n_ref_nodes, n_ref))
+        return ORBX_BAD_ARG;
+    // common nodes in ascending order; where the reference would index out of range (row idx of the reference
+    // descriptors, matched[ref_idx]) the call is rejected
+    std::vector<int32_t> jobs;
+    for (int f = 0, rf = 0; f < n_nodes && rf < n_ref_nodes;) {
+        if (node_ids[f] == ref_node_ids[rf]) {
+            const int rlen = ref_node_start[rf + 1] - ref_node_start[rf];
+            bool any_free = false;
+            for (int b = node_start[f]; b < node_start[f + 1]; b++) {
+                const int idx = node_items[b];
+                if (has_point[idx]) continue;
+                if (idx >= n_ref) return ORBX_BAD_ARG;
+                any_free = true;
+            }
+            if (any_free)
+                for (int a = ref_node_start[rf]; a < ref_node_start[rf + 1]; a++)
+                    if (ref_node_items[a] >= n) return ORBX_BAD_ARG;
+            jobs.push_back(node_start[f]);
+            jobs.push_back(node_start[f + 1] - node_start[f]);
+            jobs.push_back(ref_node_start[rf]);
+            jobs.push_back(rlen);
+            f++;
+            rf++;
+        } else if (ref_node_ids[rf] < node_ids[f]) rf++;
+        else f++;
+    }
+    const int n_jobs = (int)(jobs.size() / 4);
+    if (n_jobs == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int n_items = node_start[n_nodes], n_ref_items = ref_node_start[n_ref_nodes];
+    ORBX_TRY(h->d_kp.ensure(n));
+    ORBX_TRY(h->d_refkp.ensure(n_ref));
+    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
+    ORBX_TRY(h->d_t.ensure((size_t)n_ref * 32));
+    ORBX_TRY(h->d_flags.ensure((size_t)n + n_ref));
+    ORBX_TRY(h->d_items.ensure((size_t)std::max(n_items, 1) + std::max(n_ref_items, 1)));
+    ORBX_TRY(h->d_ints.ensure((size_t)4 * n_jobs));
+    ORBX_TRY(h->d_idx.ensure(n));
+    ORBX_TRY(h->d_dist.ensure(n));
+    ORBX_TRY(h->d_pushes.ensure((size_t)2 * n + 2));
+    ORBX_TRY(h->d_f2.ensure(n_levels));
+    int32_t* d_ref_items = h->d_items.p + std::max(n_items, 1);
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, keypoints, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_refkp.p, ref_keypoints, sizeof(orbx_keypoint) * n_ref, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_q.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_t.p, ref_descriptors, (size_t)n_ref * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_flags.p, has_point, n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_flags.p + n, ref_has_point, n_ref, hipMemcpyHostToDevice, s));
+    if (n_items > 0)
+        ORBX_HIP(hipMemcpyAsync(h->d_items.p, node_items, sizeof(int32_t) * n_items, hipMemcpyHostToDevice, s));
+    if (n_ref_items > 0)
+        ORBX_HIP(hipMemcpyAsync(d_ref_items, ref_node_items, sizeof(int32_t) * n_ref_items, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_ints.p, jobs.data(), sizeof(int32_t) * jobs.size(), hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_sigmas, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    EpiArgs A;
+    A.kps = h->d_kp.p;
+    A.n = n;
+    A.desc = h->d_q.p;
+    A.ref_kps = h->d_refkp.p;
+    A.n_ref = n_ref;
+    A.ref_desc = h->d_t.p;
+    A.has_mp = h->d_flags.p;
+    A.ref_has_mp = h->d_flags.p + n;
+    for (int i = 0; i < 9; i++) A.F[i] = fundamental[i];
+    A.scale_sigmas = h->d_f2.p;
+    A.n_levels = n_levels;
+    A.jobs = h->d_ints.p;
+    A.n_jobs = n_jobs;
+    A.items = h->d_items.p;
+    A.ref_items = d_ref_items;
+    A.low_threshold = low_threshold;
+    A.check_orientation = check_orientation;
+    A.matched = h->d_idx.p;
+    A.dists = h->d_dist.p;
+    A.pushes = h->d_pushes.p;
+    const size_t shmem = sizeof(int32_t) * (size_t)n + sizeof(unsigned short) * (size_t)n;
+    hipLaunchKernelGGL(k_epipolar_match, dim3(1), dim3(64), shmem, s, A);
+    ORBX_HIP(hipGetLastError());
+    std::vector<int32_t> matched(n), dists(n);
+    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    int c = 0;  // MatcherBase::createMatches (orb_matcher.h:81-93)
+    for (int i = 0; i < n; i++)
+        if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
+    *count = c;
+    return ORBX_OK;
+}
+
+orbx_status orbx_fuse_search(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start, const int32_t* cell_items,
+                             const orbx_keypoint* keypoints, int n, const uint8_t* descriptors, int n_points,
+                             const uint8_t* in_view, const float* proj_xy, const int32_t* pred_level,
+                             const uint8_t* point_descriptors, const float* scale_factors,
+                             const float* inv_scale_sigmas, int n_levels, float radius_multiplier,
+                             int32_t* best_index, int32_t* best_distance) {
+    if (!h || !g || n < 0 || n_points < 0) return ORBX_BAD_ARG;
+    if (n_points == 0) return ORBX_OK;
+    if (!best_index || !best_distance) return ORBX_BAD_ARG;
+    if (n == 0) {
+        for (int p = 0; p < n_points; p++) { best_index[p] = -1; best_distance[p] = 256; }
+        return ORBX_OK;
+    }
+    if (!cell_start || !cell_items || !keypoints || !descriptors || !in_view || !proj_xy || !pred_level ||
+        !point_descriptors || !scale_factors || !inv_scale_sigmas)
+        return ORBX_BAD_ARG;
+    if (g->grid_cols <= 0 || g->grid_rows <= 0 || g->grid_size_x <= 0 || g->grid_size_y <= 0 || n_levels <= 0)
+        return ORBX_BAD_ARG;
+    const int ncell = g->grid_cols * g->grid_rows;
+    if (cell_start[0] != 0 || cell_start[ncell] != n) return ORBX_BAD_ARG;
+    for (int c = 0; c < ncell; c++)
+        if (cell_start[c + 1] < cell_start[c]) return ORBX_BAD_ARG;
+    for (int i = 0; i < n; i++) {
+        if (cell_items[i] < 0 || cell_items[i] >= n) return ORBX_BAD_ARG;
+        if (keypoints[i].octave >= n_levels) return ORBX_BAD_ARG;
+    }
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_cells.ensure(ncell + 1));
+    ORBX_TRY(h->d_items.ensure(n));
+    ORBX_TRY(h->d_kp.ensure(n));
+    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
+    ORBX_TRY(h->d_t.ensure((size_t)n_points * 32));
+    ORBX_TRY(h->d_flags.ensure(n_points));
+    ORBX_TRY(h->d_f0.ensure((size_t)2 * n_points));
+    ORBX_TRY(h->d_f2.ensure((size_t)2 * n_levels));
+    ORBX_TRY(h->d_ints.ensure(n_points));
+    ORBX_TRY(h->d_idx.ensure(n_points));
+    ORBX_TRY(h->d_dist.ensure(n_points));
+    ORBX_HIP(hipMemcpyAsync(h->d_cells.p, cell_start, sizeof(int32_t) * (ncell + 1), hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_items.p, cell_items, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, keypoints, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_q.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_t.p, point_descriptors, (size_t)n_points * 32, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_flags.p, in_view, n_points, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f0.p, proj_xy, sizeof(float) * 2 * n_points, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_factors, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p + n_levels, inv_scale_sigmas, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_ints.p, pred_level, sizeof(int32_t) * n_points, hipMemcpyHostToDevice, s));
+    FuseArgs A;
+    A.g = *g;
+    A.cell_start = h->d_cells.p;
+    A.cell_items = h->d_items.p;
+    A.kps = h->d_kp.p;
+    A.desc = h->d_q.p;
+    A.n_pts = n_points;
+    A.in_view = h->d_flags.p;
+    A.proj_xy = h->d_f0.p;
+    A.pred_level = h->d_ints.p;
+    A.pt_desc = h->d_t.p;
+    A.scale_factors = h->d_f2.p;
+    A.inv_scale_sigmas = h->d_f2.p + n_levels;
+    A.n_levels = n_levels;
+    A.radius_multiplier = radius_multiplier;
+    A.best_idx = h->d_idx.p;
+    A.best_dist = h->d_dist.p;
+    hipLaunchKernelGGL(k_fuse_search, dim3(div_up(n_points, 16)), dim3(256), 0, s, A);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(best_index, h->d_idx.p, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(best_distance, h->d_dist.p, sizeof(int32_t) * n_points, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
     return ORBX_OK;
 }
 

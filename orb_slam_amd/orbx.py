@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -382,6 +382,49 @@ class Matcher:
                                     int(low_threshold), C.c_float(nn_ratio), int(bool(check_orientation)), _p(out),
                                     C.byref(n)), "orbx_match_bow")
         return out[:n.value].copy()
+
+    def match_epipolar(self, kps, desc, ref_kps, ref_desc, has_point, ref_has_point, F, scale_sigmas, nodes,
+                       ref_nodes, low_threshold=50, check_orientation=True):
+        """nodes / ref_nodes as in match_bow; F = 3x3 float32 fundamental matrix."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+        has = np.ascontiguousarray(has_point, np.uint8)
+        ref_has = np.ascontiguousarray(ref_has_point, np.uint8)
+        F = np.ascontiguousarray(F, np.float32).reshape(9)
+        sig = np.ascontiguousarray(scale_sigmas, np.float32)
+        ni, ns, nit = (np.ascontiguousarray(nodes[0], np.uint32), np.ascontiguousarray(nodes[1], np.int32),
+                       np.ascontiguousarray(nodes[2], np.int32))
+        ri, rs, rit = (np.ascontiguousarray(ref_nodes[0], np.uint32), np.ascontiguousarray(ref_nodes[1], np.int32),
+                       np.ascontiguousarray(ref_nodes[2], np.int32))
+        out = np.zeros(max(len(kps), 1), MATCH_DTYPE)
+        n = C.c_int()
+        _check(lib().orbx_match_epipolar(self._h, _p(kps), len(kps), _p(desc), _p(ref_kps), len(ref_kps),
+                                         _p(ref_desc), _p(has), _p(ref_has), _p(F), _p(sig), len(sig), _p(ni), _p(ns),
+                                         _p(nit), len(ni), _p(ri), _p(rs), _p(rit), len(ri), int(low_threshold),
+                                         int(bool(check_orientation)), _p(out), C.byref(n)), "orbx_match_epipolar")
+        return out[:n.value].copy()
+
+    def fuse_search(self, g, start, items, kps, desc, in_view, proj_xy, pred_level, pt_desc, scale_factors,
+                    inv_scale_sigmas, radius_multiplier):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        in_view = np.ascontiguousarray(in_view, np.uint8)
+        proj_xy = np.ascontiguousarray(proj_xy, np.float32)
+        pred_level = np.ascontiguousarray(pred_level, np.int32)
+        pt_desc = np.ascontiguousarray(pt_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        inv = np.ascontiguousarray(inv_scale_sigmas, np.float32)
+        start = np.ascontiguousarray(start, np.int32)
+        items = np.ascontiguousarray(items, np.int32)
+        best_idx = np.zeros(max(len(in_view), 1), np.int32)
+        best_dist = np.zeros(max(len(in_view), 1), np.int32)
+        _check(lib().orbx_fuse_search(self._h, C.byref(g), _p(start), _p(items), _p(kps), len(kps), _p(desc),
+                                      len(in_view), _p(in_view), _p(proj_xy), _p(pred_level), _p(pt_desc), _p(sf),
+                                      _p(inv), len(sf), C.c_float(radius_multiplier), _p(best_idx), _p(best_dist)),
+               "orbx_fuse_search")
+        return best_idx[:len(in_view)].copy(), best_dist[:len(in_view)].copy()
 
 
 def filter_matches_host(matches, n_descriptor_rows):

@@ -10,21 +10,76 @@
 using namespace orb_slam;
 using namespace orb_slam::geometry;
 
-// the slice of Frame / KeyFrame / MapPoint that ORBMatcher::matchByBowFeatures touches
-struct MockMapPoint { bool bad = false; bool isBad() const { return bad; } };
+// the slice of Frame / KeyFrame / MapPoint / Camera that the ORBMatcher templates touch
+struct MockTrackProperties {
+    bool in_view_ = false;
+    cv::Point2f proj_xy_;
+    int pred_scale_level_ = 0;
+    float view_cosine_ = 1.f;
+};
+struct MockKeyFrame;
+struct MockMapPoint {
+    bool bad = false;
+    int n_obs = 1;
+    cv::Point2f img;     // where the mock frustum test projects the point
+    int level = 0;
+    cv::Mat desc;
+    MockTrackProperties props;
+    std::vector<std::pair<const MockKeyFrame*, int>> obs;
+    bool isBad() const { return bad; }
+    void resetTrackProperties() { props.in_view_ = false; }
+    void setTrackProperties(const MockTrackProperties& p) { props = p; }
+    const MockTrackProperties& trackProperties() const { return props; }
+    const cv::Mat& bestDescriptor() const { return desc; }
+    int nObservations() const { return n_obs; }
+    bool isObservedInKeyFrame(const std::shared_ptr<MockKeyFrame>& kf) const {
+        for (auto& o : obs) if (o.first == kf.get()) return true;
+        return false;
+    }
+    void addObservation(const std::shared_ptr<MockKeyFrame>& kf, int idx) { obs.emplace_back(kf.get(), idx); n_obs++; }
+    void replace(const std::shared_ptr<MockMapPoint>&) { bad = true; }
+};
+struct MockCamera {
+    float minX() const { return 0.f; }
+    float minY() const { return 0.f; }
+    float maxX() const { return 640.f; }
+    float maxY() const { return 480.f; }
+    float undistWidth() const { return 640.f; }
+    float undistHeight() const { return 480.f; }
+};
 struct MockFrame {
     std::vector<cv::KeyPoint> kps;
     cv::Mat desc;
     std::map<unsigned, std::vector<unsigned>> bow;
+    std::shared_ptr<MockCamera> cam = std::make_shared<MockCamera>();
+    std::shared_ptr<ORBExtractor> extractor;
     const std::vector<cv::KeyPoint>& featuresUndist() const { return kps; }
     const cv::Mat& descriptorsUndist() const { return desc; }
     const std::map<unsigned, std::vector<unsigned>>& bowFeatures() const { return bow; }
+    const std::shared_ptr<MockCamera>& camera() const { return cam; }
+    const std::shared_ptr<ORBExtractor>& orbExtractor() const { return extractor; }
+    int gridCols() const { return 64; }
+    int gridRows() const { return 64; }
+    bool isInCameraView(const std::shared_ptr<MockMapPoint>& mp, MockTrackProperties& p, float) const {
+        p.in_view_ = true; p.proj_xy_ = mp->img; p.pred_scale_level_ = mp->level; p.view_cosine_ = 1.f;
+        return true;
+    }
 };
 struct MockKeyFrame {
     std::shared_ptr<MockFrame> f;
     std::vector<std::shared_ptr<MockMapPoint>> mps;
     const std::shared_ptr<MockFrame>& frame() const { return f; }
     std::vector<std::shared_ptr<MockMapPoint>> obsMapPoints() const { return mps; }
+    void updateWorldInCamLocal() {}
+    bool isInCameraViewLocal(const std::shared_ptr<MockMapPoint>& mp, MockTrackProperties& p, float lim) const {
+        return f->isInCameraView(mp, p, lim);
+    }
+    void setMapPointAt(const std::shared_ptr<MockMapPoint>& mp, int idx) { mps[idx] = mp; }
+    void computeFundamentalMat(cv::Mat& F, const std::shared_ptr<MockKeyFrame>&) const {
+        F.create(3, 3, CV_32F);  // pure translation along x: epipolar lines are the image rows
+        const float v[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
+        std::memcpy(F.data, v, sizeof(v));
+    }
 };
 
 int main(int argc, char** argv) {
@@ -60,6 +115,31 @@ int main(int argc, char** argv) {
         std::vector<cv::DMatch> mb;
         mt.matchByBowFeatures(fa, kf, mb, true, 0.6f);
         std::printf("bow_matches=%zu\n", mb.size());
+        // map-point projection matcher, epipolar matcher and fuse on the same features
+        auto shared_ex = std::make_shared<ORBExtractor>(nh, 640, 480);
+        fa->extractor = shared_ex; fb->extractor = shared_ex;
+        std::vector<std::shared_ptr<MockMapPoint>> pts;
+        for (size_t i = 0; i < k1.size(); i++) {
+            auto mp = std::make_shared<MockMapPoint>();
+            mp->img = k1[i].pt; mp->level = k1[i].octave;
+            mp->desc.create(1, 32, CV_8U);
+            std::memcpy(mp->desc.data, d1.data + 32 * i, 32);
+            pts.push_back(i % 7 ? mp : nullptr);
+        }
+        std::vector<cv::DMatch> mp_matches;
+        mt.matchByProjection(fa, pts, mp_matches, true, 0.6f, 1.0f);
+        std::printf("point_matches=%zu\n", mp_matches.size());
+        auto ka = std::make_shared<MockKeyFrame>(), kb = std::make_shared<MockKeyFrame>();
+        ka->f = fa; kb->f = fb;
+        ka->mps.assign(k1.size(), nullptr); kb->mps.assign(k2.size(), nullptr);
+        std::vector<cv::DMatch> me;
+        mt.matchByEpipolarConstraint(ka, kb, me, true);
+        std::printf("epipolar_matches=%zu\n", me.size());
+        const int fused = mt.fuse(ka, pts, 3.0f);
+        size_t attached = 0;
+        for (auto& m2 : ka->mps) attached += m2 ? 1 : 0;
+        const int fused_again = mt.fuse(ka, pts, 3.0f);
+        std::printf("fused=%d attached=%zu fused_again=%d\n", fused, attached, fused_again);
     }
     Initializer init(1.0, 50);
     std::vector<cv::Point2f> p, r;

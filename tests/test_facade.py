@@ -34,3 +34,9 @@ def test_facade_runs_on_gpu():
     assert kp > 300 and f"desc={kp}" in out and f"matches=" in out
     assert "sf1=1.20000005" in out
     assert int(out.split("bow_matches=")[1].split()[0]) > kp // 2
+    assert int(out.split("point_matches=")[1].split()[0]) > kp // 2
+    assert int(out.split("epipolar_matches=")[1].split()[0]) > kp // 5
+    fused = int(out.split("fused=")[1].split()[0])
+    attached = int(out.split("attached=")[1].split()[0])
+    assert fused > kp // 2 and 0 < attached <= fused
+    assert int(out.split("fused_again=")[1].split()[0]) == 0

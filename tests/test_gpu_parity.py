@@ -520,6 +520,86 @@ def test_bow_matcher_bit_exact(oracle, matcher, ex1000, test_images):
         matcher.match_bow(k0, d0, k1, d1, has, bad, ref_nodes)
 
 
+def test_epipolar_matcher_bit_exact(oracle, matcher, ex1000, test_images):
+    """EpipolarConstraintWithBowMatcher::match (orb_matcher.cpp:520-661), quirks included: the distance is taken
+    between row idx of both descriptor matrices, so the reference frame is a perturbed copy of the frame (same row
+    order) for the test to produce matches at all."""
+    rng = np.random.default_rng(83)
+    k0, d0 = ex1000.compute(test_images[0], ex1000.detect(test_images[0]))
+    n = len(k0)
+    _, _, _, sig, _ = ex1000.scale_tables()
+    flips = (rng.uniform(size=(n, 256)) < rng.uniform(0.0, 0.25, (n, 1))).astype(np.uint8)
+    d1 = d0 ^ np.packbits(flips, axis=1)
+    k1 = k0.copy()
+    k1["x"] += rng.normal(0, 3, n).astype(np.float32)
+    k1["y"] += rng.normal(0, 1.5, n).astype(np.float32)
+    k1["angle"] = np.mod(k1["angle"] + rng.normal(0, 20, n), 360).astype(np.float32)
+    k1["octave"] = np.clip(k1["octave"] + rng.integers(-1, 2, n), 0, 7)
+    has = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    ref_has = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    F_tx = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # pure x translation: rows are epipolar lines
+    A = rng.normal(size=(3, 3))
+    u, w, vt = np.linalg.svd(A)
+    F_gen = (u @ np.diag([w[0], w[1], 0]) @ vt).astype(np.float32) * 1e-3
+    total = 0
+    for n_nodes, drop in ((1, 0.0), (8, 0.0), (40, 0.2), (300, 0.3)):
+        nodes = _feature_vector(d0, rng, n_nodes, drop)
+        ref_nodes = _feature_vector(d1, rng, n_nodes, drop)
+        for F in (F_tx, F_gen, np.zeros((3, 3), np.float32)):
+            for low, orient in ((50, True), (80, False), (20, True)):
+                m = matcher.match_epipolar(k0, d0, k1, d1, has, ref_has, F, sig, nodes, ref_nodes, low, orient)
+                om = oracle.match_epipolar(k0, d0, k1, d1, has, ref_has, F, sig, nodes, ref_nodes, low, orient)
+                assert np.array_equal(m, om.astype(orbx.MATCH_DTYPE)), (n_nodes, low, orient)
+                total += len(m) if F is F_tx else 0
+    assert total > 200
+    # a node index the reference would use beyond the other frame's arrays
+    nodes = _feature_vector(d0, rng, 8)
+    short = _feature_vector(d1[:n // 2], rng, 8)
+    assert oracle.match_epipolar(k0, d0, k1[:n // 2], d1[:n // 2], has * 0, ref_has, F_tx, sig, nodes, short, 50,
+                                 True) is None
+    with pytest.raises(orbx.OrbxError):
+        matcher.match_epipolar(k0, d0, k1[:n // 2], d1[:n // 2], has * 0, ref_has, F_tx, sig, nodes, short)
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    assert len(matcher.match_epipolar(k0, d0, k1, d1, has, ref_has, F_tx, sig, e, ref_nodes)) == 0
+
+
+def test_fuse_search_bit_exact(oracle, matcher, ex1000, test_images):
+    """Candidate search of ORBMatcher::fuse (orb_matcher.cpp:806-867) against the oracle."""
+    rng = np.random.default_rng(87)
+    bounds = (10.803785, 626.0599, 14.68408, 473.3248)
+    g = orbx.make_grid(bounds)
+    og = oracle.grid_params(bounds)
+    k0, start, items = orbx.assign_grid(g, ex1000.detect(test_images[0]))
+    k0, d0 = ex1000.compute(test_images[0], k0)
+    _, sf, _, _, inv_sig = ex1000.scale_tables()
+    n = len(k0)
+    # map points: most sit near a feature of the key frame and carry a noisy copy of its descriptor
+    n_pts = 3000
+    src = rng.integers(0, n, n_pts)
+    proj = np.stack([k0["x"][src], k0["y"][src]], 1) + rng.normal(0, 1.5, (n_pts, 2)).astype(np.float32)
+    proj[:7] = [[-3, 5], [700, 100], [320, -2], [320, 500], [11, 15], [626, 473], [5000, 5000]]
+    flips = (rng.uniform(size=(n_pts, 256)) < rng.uniform(0.0, 0.3, (n_pts, 1))).astype(np.uint8)
+    pd = d0[src] ^ np.packbits(flips, axis=1)
+    pred = np.clip(k0["octave"][src] + rng.integers(-1, 2, n_pts), 0, 7).astype(np.int32)
+    in_view = (rng.uniform(size=n_pts) > 0.1).astype(np.uint8)
+    hits = 0
+    for mult in (3.0, 1.0, 10.0, 0.2):
+        bi, bd = matcher.fuse_search(g, start, items, k0, d0, in_view, proj, pred, pd, sf, inv_sig, mult)
+        oi, od = oracle.fuse_search(og, start, items, k0, d0, in_view, proj, pred, pd, sf, inv_sig, mult)
+        assert np.array_equal(bi, oi) and np.array_equal(bd, od), mult
+        hits = max(hits, int((bd <= 50).sum()))
+    assert hits > 500
+    assert (bi[in_view == 0] == -1).all()
+    # ties: identical descriptors everywhere -> the first feature in scan order wins
+    same = np.zeros_like(d0)
+    bi, bd = matcher.fuse_search(g, start, items, k0, same, in_view, proj, pred, np.zeros_like(pd), sf, inv_sig, 10.0)
+    oi, od = oracle.fuse_search(og, start, items, k0, same, in_view, proj, pred, np.zeros_like(pd), sf, inv_sig, 10.0)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+    # no points / no features
+    bi, bd = matcher.fuse_search(g, start, items, k0, d0, in_view[:0], proj[:0], pred[:0], pd[:0], sf, inv_sig, 3.0)
+    assert len(bi) == 0
+
+
 def test_best_descriptor_batch_bit_exact(oracle, matcher):
     """MapPoint::computeBestDescriptor (map_point.cpp:109-166) for a batch of observation sets."""
     rng = np.random.default_rng(71)
