@@ -5,6 +5,11 @@
  * findFundamentalAndHomography / the getters are the reference's own test seam.  One additive seam:
  * setRansacSets() injects the 8-index sets; without it they are drawn as in the reference (std::shuffle seeded
  * from std::random_device, cumulative over iterations, Initializer.cpp:261-277).
+ *
+ * Pose recovery (Initializer.cpp:30-252): tryToInitialize, findRtWithFundamental and triangulatePoints keep the
+ * reference's signatures, minus the frame argument (the frame only supplies the matched points, :44-53, which
+ * arrive here through setPoints / setRefPoints); the camera enters as its 3x3 intrinsic matrix (CV_32F, what
+ * camera_->intrinsicMatrix() returns) through setIntrinsicMatrix().
  */
 #pragma once
 
@@ -30,6 +35,96 @@ public:
     void setRefPoints(const std::vector<cv::Point2f>& ref_points) { ref_points_ = ref_points; }
     void setPoints(const std::vector<cv::Point2f>& points) { points_ = points; }
     void setRansacSets(const std::vector<std::vector<size_t>>& sets) { ransac_sets_ = sets; injected_ = true; }
+    void setIntrinsicMatrix(const cv::Mat& K) { intrinsic_ = K.clone(); }
+
+    /**
+     * Initializer::tryToInitialize (Initializer.cpp:30-110) on the points given by setPoints / setRefPoints.
+     */
+    bool tryToInitialize(
+        cv::Mat& best_rot_mat,
+        cv::Mat& best_trans_mat,
+        std::vector<cv::Point2d>& inlier_points,
+        std::vector<cv::Point2d>& inlier_ref_points,
+        std::vector<cv::Point3d>& inlier_points_3d,
+        std::vector<size_t>& inliers_idxs)
+    {
+        const int n = (int)points_.size();
+        findFundamentalAndHomography();
+        float r_score = h_score_ / (h_score_ + f_score_);
+        const bool use_h = r_score > 0.40;
+        const std::vector<bool>& inl = use_h ? inliers_h_ : inliers_f_;
+        for (int i = 0; i < n; ++i) {
+            if (!inl[i]) continue;
+            const auto& p = points_[i];
+            const auto& rp = ref_points_[i];
+            inlier_points.push_back(cv::Point2d(p.x, p.y));
+            inlier_ref_points.push_back(cv::Point2d(rp.x, rp.y));
+            inliers_idxs.push_back(i);
+        }
+        if (use_h) {
+            if (!findRtWithHomography(inlier_points, inlier_ref_points, best_rot_mat, best_trans_mat)) return false;
+        } else {
+            if (!findRtWithFundamental(inlier_points, inlier_ref_points, best_rot_mat, best_trans_mat)) return false;
+        }
+        return triangulatePoints(inlier_points, inlier_ref_points, best_rot_mat, best_trans_mat, inlier_points_3d);
+    }
+
+    /**
+     * Initializer::findRtWithHomography (Initializer.cpp:112-163).  The reference hands std::vector<cv::Point2d>
+     * to cv::filterHomographyDecompByVisibleRefpoints, which in OpenCV 3.4 asserts CV_32FC2 points; the
+     * cv::Exception is caught (:150-155) and the function returns false, so the reference never initialises from
+     * a homography.  That outcome is kept; no decomposition is computed.
+     */
+    bool findRtWithHomography(
+        const std::vector<cv::Point2d>&, const std::vector<cv::Point2d>&, cv::Mat&, cv::Mat&)
+    {
+        return false;
+    }
+
+    /** Initializer::findRtWithFundamental (Initializer.cpp:165-199): R (3x3) and t (3x1) as CV_64F. */
+    bool findRtWithFundamental(
+        const std::vector<cv::Point2d>& inlier_points,
+        const std::vector<cv::Point2d>& inlier_ref_points,
+        cv::Mat& R,
+        cv::Mat& t)
+    {
+        if (fundamental_mat_.empty() || intrinsic_.empty()) return false; // cv::Exception path of the reference
+        const int32_t start[2] = {0, (int32_t)inlier_points.size()};
+        double r9[9], t3[3];
+        int32_t good = 0;
+        orbx_status st = orbx_recover_pose_batch(
+            handle_.get(), 1, fundamental_mat_.ptr<float>(), intrinsic_.ptr<float>(),
+            reinterpret_cast<const double*>(inlier_points.data()),
+            reinterpret_cast<const double*>(inlier_ref_points.data()), start, r9, t3, &good);
+        if (st != ORBX_OK) return false;
+        R.create(3, 3, CV_64F);
+        t.create(3, 1, CV_64F);
+        std::memcpy(R.data, r9, sizeof(r9));
+        std::memcpy(t.data, t3, sizeof(t3));
+        return true;
+    }
+
+    /** Initializer::triangulatePoints (Initializer.cpp:201-252). */
+    bool triangulatePoints(
+        const std::vector<cv::Point2d>& inlier_points,
+        const std::vector<cv::Point2d>& inlier_ref_points,
+        const cv::Mat& R,
+        const cv::Mat& t,
+        std::vector<cv::Point3d>& inlier_points_3d)
+    {
+        if (R.empty() || t.empty() || intrinsic_.empty()) return false; // cv::hconcat / gemm would throw
+        const int n = (int)inlier_points.size();
+        const int32_t start[2] = {0, n};
+        std::vector<cv::Point3d> out(n);
+        orbx_status st = orbx_triangulate_batch(
+            handle_.get(), 1, intrinsic_.ptr<float>(), R.ptr<double>(), t.ptr<double>(),
+            reinterpret_cast<const double*>(inlier_points.data()),
+            reinterpret_cast<const double*>(inlier_ref_points.data()), start,
+            reinterpret_cast<double*>(out.data()));
+        if (st != ORBX_OK) return false;
+        inlier_points_3d.insert(inlier_points_3d.end(), out.begin(), out.end());
+        return true;
+    }
 
     const cv::Mat& getFundamentalMat() const { return fundamental_mat_; }
     const cv::Mat& getHomographyMat() const { return homography_mat_; }
@@ -81,7 +176,7 @@ private:
     bool injected_ = false;
     std::vector<cv::Point2f> points_, ref_points_;
     std::vector<std::vector<size_t>> ransac_sets_;
-    cv::Mat fundamental_mat_, homography_mat_;
+    cv::Mat fundamental_mat_, homography_mat_, intrinsic_;
     std::vector<bool> inliers_f_, inliers_h_;
     double f_score_ = 0.0, h_score_ = 0.0;
     std::shared_ptr<orbx_ransac> handle_;

@@ -26,6 +26,7 @@
 #define ORBX_HAVE_OPENCV 0
 #define CV_8U 0
 #define CV_32F 5
+#define CV_64F 6
 namespace cv {
 template <typename T> struct Point_ {
     T x, y;
@@ -34,6 +35,12 @@ template <typename T> struct Point_ {
 };
 typedef Point_<float> Point2f;
 typedef Point_<double> Point2d;
+template <typename T> struct Point3_ {
+    T x, y, z;
+    Point3_() : x(0), y(0), z(0) {}
+    Point3_(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
+};
+typedef Point3_<double> Point3d;
 struct KeyPoint {
     Point2f pt;
     float size, angle, response;
@@ -54,7 +61,7 @@ public:
     Mat(int r, int c, int type) { create(r, c, type); }
     void create(int r, int c, int type) {
         rows = r; cols = c; type_ = type & 7; ch_ = ((type >> 3) & 511) + 1;
-        esz_ = (type_ == CV_32F ? 4 : 1) * ch_;
+        esz_ = (type_ == CV_64F ? 8 : type_ == CV_32F ? 4 : 1) * ch_;
         buf_ = std::make_shared<std::vector<unsigned char>>((size_t)r * c * esz_);
         data = buf_->data();
         step = (size_t)c * esz_;

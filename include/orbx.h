@@ -288,6 +288,24 @@ orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float*
                                const uint32_t* sets8, int iterations, double sigma,
                                float* F_all, float* H_all, float* Hinv_all, float* score_f, float* score_h);
 
+/* Replaces Initializer::findRtWithFundamental (src/Initializer.cpp:165-199) for a batch of frame pairs: E = K^T F K
+   as the reference forms it (CV_32F), then cv::recoverPose(E, inlier_ref_points, inlier_points, R, t, focal, pp) of
+   OpenCV 3.4 in double (decomposeEssentialMat, triangulation of every correspondence against the four candidate
+   poses, cheirality count with the distance limit 50).  fundamental: n_pairs x 9 (row-major, float);
+   intrinsics: the camera's 3x3 intrinsicMatrix() (float); points / ref_points: the inlier correspondences of all
+   pairs back to back as (x, y) doubles, pair p owning rows pair_start[p] .. pair_start[p + 1].
+   Out: rotation n_pairs x 9, translation n_pairs x 3, n_good = recoverPose's return value. */
+orbx_status orbx_recover_pose_batch(orbx_ransac* h, int n_pairs, const float* fundamental, const float* intrinsics,
+                                    const double* points, const double* ref_points, const int32_t* pair_start,
+                                    double* rotation, double* translation, int32_t* n_good);
+
+/* Replaces Initializer::triangulatePoints (src/Initializer.cpp:201-252): cv::triangulatePoints with
+   projection = K [R | t] and projection_ref = K [I | 0], each point divided by its fourth coordinate.
+   points_3d: one (x, y, z) per correspondence, in the order of points. */
+orbx_status orbx_triangulate_batch(orbx_ransac* h, int n_pairs, const float* intrinsics, const double* rotation,
+                                   const double* translation, const double* points, const double* ref_points,
+                                   const int32_t* pair_start, double* points_3d);
+
 /* The reference's set generator (Initializer.cpp:261-277: cumulative std::shuffle, first 8) with a caller-chosen
    seed per iteration (seed0 + it) in place of std::random_device.  Host arithmetic. */
 orbx_status orbx_ransac_make_sets(int n, int iterations, uint32_t seed0, uint32_t* sets8);

@@ -167,6 +167,19 @@ void orc_ransac_fh(const float* pts, const float* ref, int n, const uint32_t* se
 void orc_ransac_fh_all(const float* pts, const float* ref, int n, const uint32_t* sets8, int iterations, double sigma,
                        float* F_all, float* H_all, float* Hinv_all, float* score_f, float* score_h);
 
+/* ---- pose recovery after RANSAC (Initializer.cpp:165-252); OpenCV parts restated, parity unpinned ---- */
+/* cv::SVD::compute on a square CV_64F matrix (flags 0): w descending, u (n x n), vt (n x n). u / vt may be NULL. */
+void orc_svd_square_f64(const double* A, int n, double* w, double* u, double* vt);
+/* cv::triangulatePoints: P1, P2 3x4 row-major, x1 / x2 n points (x, y) -> n homogeneous points (x, y, z, w). */
+void orc_triangulate_points(const double* P1, const double* P2, const double* x1, const double* x2, int n,
+                            double* out4);
+/* Initializer::findRtWithFundamental: returns cv::recoverPose's count. */
+int  orc_recover_pose_fundamental(const float* F9, const float* K9, const double* inlier_points,
+                                  const double* inlier_ref_points, int n, double* R9, double* t3);
+/* Initializer::triangulatePoints. */
+void orc_triangulate_initial(const float* K9, const double* R9, const double* t3, const double* inlier_points,
+                             const double* inlier_ref_points, int n, double* points3);
+
 #ifdef __cplusplus
 }
 #endif

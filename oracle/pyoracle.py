@@ -352,6 +352,47 @@ def best_descriptor(desc, point_start):
     return best[:len(ps) - 1].copy()
 
 
+def svd_square_f64(A):
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[0]
+    w, u, vt = np.zeros(n), np.zeros((n, n)), np.zeros((n, n))
+    lib().orc_svd_square_f64(_p(A), n, _p(w), _p(u), _p(vt))
+    return w, u, vt
+
+
+def triangulate_points(P1, P2, x1, x2):
+    P1 = np.ascontiguousarray(P1, np.float64)
+    P2 = np.ascontiguousarray(P2, np.float64)
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+    out = np.zeros((max(len(x1), 1), 4))
+    lib().orc_triangulate_points(_p(P1), _p(P2), _p(x1), _p(x2), len(x1), _p(out))
+    return out[:len(x1)]
+
+
+def recover_pose_fundamental(F, K, pts, ref):
+    """Initializer::findRtWithFundamental -> (R, t, recoverPose's count)."""
+    F = np.ascontiguousarray(F, np.float32).reshape(9)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+    ref = np.ascontiguousarray(ref, np.float64).reshape(-1, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    lib().orc_recover_pose_fundamental.restype = C.c_int
+    good = lib().orc_recover_pose_fundamental(_p(F), _p(K), _p(pts), _p(ref), len(pts), _p(R), _p(t))
+    return R, t, good
+
+
+def triangulate_initial(K, R, t, pts, ref):
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+    ref = np.ascontiguousarray(ref, np.float64).reshape(-1, 2)
+    out = np.zeros((max(len(pts), 1), 3))
+    lib().orc_triangulate_initial(_p(K), _p(R), _p(t), _p(pts), _p(ref), len(pts), _p(out))
+    return out[:len(pts)]
+
+
 def normalize_points(xy):
     xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
     out = np.zeros_like(xy)

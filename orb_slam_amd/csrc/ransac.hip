@@ -5,6 +5,7 @@
 
 #include "common.h"
 #include "ransac_kernels.h"
+#include "pose_kernels.h"
 
 using namespace orbx;
 
@@ -19,6 +20,10 @@ struct orbx_ransac {
     DevBuf<uint32_t> d_sets;
     DevBuf<uint8_t> d_inlf, d_inlh;
     DevBuf<int32_t> d_best;
+    // pose recovery
+    DevBuf<double> d_ppts, d_pref, d_cand, d_norm, d_R, d_t, d_xyz;
+    DevBuf<float> d_K, d_Fp;
+    DevBuf<int32_t> d_pstart, d_good, d_count;
     StageTimer timer;
     float last_ms[RT_COUNT] = {};
 };
@@ -133,6 +138,9 @@ void orbx_ransac_destroy(orbx_ransac* h) {
     h->d_Fall.release(); h->d_Hall.release(); h->d_Hiall.release(); h->d_sf.release(); h->d_sh.release();
     h->d_F.release(); h->d_H.release(); h->d_scores.release(); h->d_sets.release(); h->d_inlf.release();
     h->d_inlh.release(); h->d_best.release();
+    h->d_ppts.release(); h->d_pref.release(); h->d_cand.release(); h->d_norm.release(); h->d_R.release();
+    h->d_t.release(); h->d_xyz.release(); h->d_K.release(); h->d_Fp.release(); h->d_pstart.release();
+    h->d_good.release(); h->d_count.release();
     h->timer.destroy();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -225,6 +233,102 @@ orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float*
     if (Hinv_all) ORBX_HIP(hipMemcpyAsync(Hinv_all, h->d_Hiall.p, m, hipMemcpyDeviceToHost, s));
     if (score_f) ORBX_HIP(hipMemcpyAsync(score_f, h->d_sf.p, sizeof(float) * iterations, hipMemcpyDeviceToHost, s));
     if (score_h) ORBX_HIP(hipMemcpyAsync(score_h, h->d_sh.p, sizeof(float) * iterations, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Validates pair_start and uploads the two double point sets; returns the total and the longest pair.
+orbx_status upload_pose_points(orbx_ransac* h, int n_pairs, const double* points, const double* ref_points,
+                               const int32_t* pair_start, int* total_out, int* longest_out) {
+    if (pair_start[0] != 0) return ORBX_BAD_ARG;
+    int longest = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        if (pair_start[p + 1] < pair_start[p]) return ORBX_BAD_ARG;
+        longest = std::max(longest, pair_start[p + 1] - pair_start[p]);
+    }
+    const int total = pair_start[n_pairs];
+    if (total > 0 && (!points || !ref_points)) return ORBX_BAD_ARG;
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_ppts.ensure(std::max((size_t)total * 2, (size_t)2)));
+    ORBX_TRY(h->d_pref.ensure(std::max((size_t)total * 2, (size_t)2)));
+    ORBX_TRY(h->d_pstart.ensure((size_t)n_pairs + 1));
+    if (total > 0) {
+        ORBX_HIP(hipMemcpyAsync(h->d_ppts.p, points, sizeof(double) * 2 * total, hipMemcpyHostToDevice, s));
+        ORBX_HIP(hipMemcpyAsync(h->d_pref.p, ref_points, sizeof(double) * 2 * total, hipMemcpyHostToDevice, s));
+    }
+    ORBX_HIP(hipMemcpyAsync(h->d_pstart.p, pair_start, sizeof(int32_t) * (n_pairs + 1), hipMemcpyHostToDevice, s));
+    *total_out = total;
+    *longest_out = longest;
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+orbx_status orbx_recover_pose_batch(orbx_ransac* h, int n_pairs, const float* fundamental, const float* intrinsics,
+                                    const double* points, const double* ref_points, const int32_t* pair_start,
+                                    double* rotation, double* translation, int32_t* n_good) {
+    if (!h || n_pairs < 0) return ORBX_BAD_ARG;
+    if (n_pairs == 0) return ORBX_OK;
+    if (!fundamental || !intrinsics || !pair_start || !rotation || !translation || !n_good) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int total = 0, longest = 0;
+    ORBX_TRY(upload_pose_points(h, n_pairs, points, ref_points, pair_start, &total, &longest));
+    ORBX_TRY(h->d_K.ensure(9));
+    ORBX_TRY(h->d_Fp.ensure((size_t)n_pairs * 9));
+    ORBX_TRY(h->d_cand.ensure((size_t)n_pairs * 21));
+    ORBX_TRY(h->d_norm.ensure(4));
+    ORBX_TRY(h->d_good.ensure((size_t)n_pairs * 4));
+    ORBX_TRY(h->d_R.ensure((size_t)n_pairs * 9));
+    ORBX_TRY(h->d_t.ensure((size_t)n_pairs * 3));
+    ORBX_TRY(h->d_count.ensure(n_pairs));
+    ORBX_HIP(hipMemcpyAsync(h->d_K.p, intrinsics, sizeof(float) * 9, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_Fp.p, fundamental, sizeof(float) * 9 * n_pairs, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemsetAsync(h->d_good.p, 0, sizeof(int32_t) * 4 * n_pairs, s));
+    hipLaunchKernelGGL(k_pose_candidates, dim3(div_up(n_pairs, 64)), dim3(64), 0, s, h->d_Fp.p, h->d_K.p, n_pairs,
+                       h->d_cand.p, h->d_norm.p);
+    if (longest > 0)
+        hipLaunchKernelGGL(k_pose_cheirality, dim3(div_up(longest, 256), n_pairs), dim3(256), 0, s, h->d_ppts.p,
+                           h->d_pref.p, h->d_pstart.p, h->d_cand.p, h->d_norm.p, h->d_good.p);
+    hipLaunchKernelGGL(k_pose_select, dim3(div_up(n_pairs, 64)), dim3(64), 0, s, h->d_cand.p, h->d_good.p, n_pairs,
+                       h->d_R.p, h->d_t.p, h->d_count.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(rotation, h->d_R.p, sizeof(double) * 9 * n_pairs, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(translation, h->d_t.p, sizeof(double) * 3 * n_pairs, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(n_good, h->d_count.p, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+orbx_status orbx_triangulate_batch(orbx_ransac* h, int n_pairs, const float* intrinsics, const double* rotation,
+                                   const double* translation, const double* points, const double* ref_points,
+                                   const int32_t* pair_start, double* points_3d) {
+    if (!h || n_pairs < 0) return ORBX_BAD_ARG;
+    if (n_pairs == 0) return ORBX_OK;
+    if (!intrinsics || !rotation || !translation || !pair_start) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int total = 0, longest = 0;
+    ORBX_TRY(upload_pose_points(h, n_pairs, points, ref_points, pair_start, &total, &longest));
+    if (total == 0) return ORBX_OK;
+    if (!points_3d) return ORBX_BAD_ARG;
+    ORBX_TRY(h->d_K.ensure(9));
+    ORBX_TRY(h->d_R.ensure((size_t)n_pairs * 9));
+    ORBX_TRY(h->d_t.ensure((size_t)n_pairs * 3));
+    ORBX_TRY(h->d_xyz.ensure((size_t)total * 3));
+    ORBX_HIP(hipMemcpyAsync(h->d_K.p, intrinsics, sizeof(float) * 9, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_R.p, rotation, sizeof(double) * 9 * n_pairs, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_t.p, translation, sizeof(double) * 3 * n_pairs, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_triangulate_initial, dim3(div_up(longest, 256), n_pairs), dim3(256), 0, s, h->d_K.p,
+                       h->d_R.p, h->d_t.p, h->d_ppts.p, h->d_pref.p, h->d_pstart.p, h->d_xyz.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(points_3d, h->d_xyz.p, sizeof(double) * 3 * total, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipStreamSynchronize(s));
     return ORBX_OK;
 }

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_recover_pose_batch", "orbx_triangulate_batch",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -495,6 +495,33 @@ class Ransac:
 
     def set_stream(self, stream_ptr):
         _check(lib().orbx_ransac_set_stream(self._h, C.c_void_p(stream_ptr)), "orbx_ransac_set_stream")
+
+    def recover_pose_batch(self, F, K, pts, ref, pair_start):
+        """F: pairs x 3 x 3 float32, K: 3 x 3 float32, pts / ref: total x 2 float64, pair_start: pairs + 1."""
+        F = np.ascontiguousarray(F, np.float32).reshape(-1, 9)
+        K = np.ascontiguousarray(K, np.float32).reshape(9)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        ref = np.ascontiguousarray(ref, np.float64).reshape(-1, 2)
+        ps = np.ascontiguousarray(pair_start, np.int32)
+        P = len(ps) - 1
+        R = np.zeros((max(P, 1), 3, 3), np.float64)
+        t = np.zeros((max(P, 1), 3), np.float64)
+        good = np.zeros(max(P, 1), np.int32)
+        _check(lib().orbx_recover_pose_batch(self._h, P, _p(F), _p(K), _p(pts), _p(ref), _p(ps), _p(R), _p(t),
+                                             _p(good)), "orbx_recover_pose_batch")
+        return R[:P], t[:P], good[:P]
+
+    def triangulate_batch(self, K, R, t, pts, ref, pair_start):
+        K = np.ascontiguousarray(K, np.float32).reshape(9)
+        R = np.ascontiguousarray(R, np.float64).reshape(-1, 9)
+        t = np.ascontiguousarray(t, np.float64).reshape(-1, 3)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        ref = np.ascontiguousarray(ref, np.float64).reshape(-1, 2)
+        ps = np.ascontiguousarray(pair_start, np.int32)
+        out = np.zeros((max(len(pts), 1), 3), np.float64)
+        _check(lib().orbx_triangulate_batch(self._h, len(ps) - 1, _p(K), _p(R), _p(t), _p(pts), _p(ref), _p(ps),
+                                            _p(out)), "orbx_triangulate_batch")
+        return out[:len(pts)]
 
     def fh(self, pts, ref, sets8, sigma=1.0):
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)

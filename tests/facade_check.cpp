@@ -1,4 +1,5 @@
 // Host-only compile/link check of the drop-in headers against the C ABI, plus a GPU run when asked (argv[1]=run).
+#include <cmath>
 #include <cstdio>
 #include <orb_slam/geometry/orb_extractor.h>
 #include <orb_slam/geometry/orb_matcher.h>
@@ -148,6 +149,33 @@ int main(int argc, char** argv) {
         init.setPoints(p); init.setRefPoints(r);
         init.findFundamentalAndHomography();
         std::printf("H empty=%d score_h=%.3f\n", (int)init.getHomographyMat().empty(), init.hScore());
+        // pose recovery from the fundamental matrix of a synthetic rigid scene, then triangulation
+        cv::Mat K(3, 3, CV_32F);
+        const float kv[9] = {525.f, 0.f, 319.5f, 0.f, 525.f, 239.5f, 0.f, 0.f, 1.f};
+        std::memcpy(K.data, kv, sizeof(kv));
+        std::vector<cv::Point2f> sp, sr;
+        unsigned q = 7;
+        auto rnd = [&]() { q = q * 1664525u + 1013904223u; return (q >> 8) / 16777216.0; };
+        for (int i = 0; i < 300; i++) {
+            const double X = rnd() * 4 - 2, Y = rnd() * 3 - 1.5, Z = 2 + rnd() * 4, a = 0.05;
+            const double x2 = std::cos(a) * X + std::sin(a) * Z + 0.3, y2 = Y + 0.02, z2 = -std::sin(a) * X + std::cos(a) * Z + 0.05;
+            sr.emplace_back((float)(525 * X / Z + 319.5), (float)(525 * Y / Z + 239.5));
+            sp.emplace_back((float)(525 * x2 / z2 + 319.5), (float)(525 * y2 / z2 + 239.5));
+        }
+        Initializer init2(1.0, 200);
+        init2.setPoints(sp); init2.setRefPoints(sr); init2.setIntrinsicMatrix(K);
+        init2.findFundamentalAndHomography();
+        std::vector<cv::Point2d> ip, ir;
+        for (size_t i = 0; i < sp.size(); i++)
+            if (init2.getInliersF()[i]) { ip.emplace_back(sp[i].x, sp[i].y); ir.emplace_back(sr[i].x, sr[i].y); }
+        cv::Mat Rm, tm;
+        std::vector<cv::Point3d> xyz;
+        const bool ok_rt = init2.findRtWithFundamental(ip, ir, Rm, tm);
+        const bool ok_tri = ok_rt && init2.triangulatePoints(ip, ir, Rm, tm, xyz);
+        int in_front = 0;
+        for (auto& P3 : xyz) in_front += P3.z > 0;
+        std::printf("pose ok=%d tri=%d inliers=%zu in_front=%d r00=%.4f tx=%.3f\n", (int)ok_rt, (int)ok_tri, ip.size(),
+                    in_front, ok_rt ? Rm.at<double>(0, 0) : 0.0, ok_rt ? tm.at<double>(0, 0) : 0.0);
     }
     return 0;
 }

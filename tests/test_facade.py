@@ -40,3 +40,9 @@ def test_facade_runs_on_gpu():
     attached = int(out.split("attached=")[1].split()[0])
     assert fused > kp // 2 and 0 < attached <= fused
     assert int(out.split("fused_again=")[1].split()[0]) == 0
+    pose = out.split("pose ok=")[1]
+    assert pose.startswith("1 tri=1")
+    inl = int(pose.split("inliers=")[1].split()[0])
+    assert inl > 250 and int(pose.split("in_front=")[1].split()[0]) == inl
+    assert abs(float(pose.split("r00=")[1].split()[0]) - 0.9988) < 2e-3   # cos(0.05)
+    assert float(pose.split("tx=")[1].split()[0]) > 0.9                   # t = (0.3, 0.02, 0.05) normalised

@@ -600,6 +600,68 @@ def test_fuse_search_bit_exact(oracle, matcher, ex1000, test_images):
     assert len(bi) == 0
 
 
+def _fundamental_of(K, R, t):
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(K)
+    F = Ki.T @ tx @ R @ Ki
+    return (F / np.linalg.norm(F)).astype(np.float32)
+
+
+def test_pose_recovery_and_triangulation_bit_exact(oracle, ransac):
+    """Initializer::findRtWithFundamental / triangulatePoints (Initializer.cpp:165-252) for a batch of pairs:
+    rotation, translation, cheirality count and every triangulated point equal the oracle's doubles bit for bit."""
+    rng = np.random.default_rng(97)
+    K = np.array([[517.3, 0, 318.6], [0, 516.5, 255.3], [0, 0, 1]], np.float32)
+    Kd = K.astype(np.float64)
+    sizes = [0, 1, 7, 8, 63, 64, 65, 255, 256, 257, 700, 2000] + rng.integers(8, 400, 20).tolist()
+    Fs, pts_l, ref_l = [], [], []
+    for p, n in enumerate(sizes):
+        a, b = rng.uniform(-0.15, 0.15, 2)
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        R = Ry @ Rx
+        t = rng.normal(size=3) * [0.4, 0.1, 0.2]
+        X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n),
+                      np.full(n, 4.0) if p % 5 == 4 else rng.uniform(1.5, 7, n)], 1)
+        x1 = (Kd @ X.T).T
+        x2 = (Kd @ (R @ X.T + t[:, None])).T
+        ref = x1[:, :2] / x1[:, 2:]
+        pts = x2[:, :2] / x2[:, 2:] + rng.normal(0, 0.5, (n, 2))
+        # the reference widens float keypoint coordinates to double (Initializer.cpp:70-71)
+        pts = pts.astype(np.float32).astype(np.float64)
+        ref = ref.astype(np.float32).astype(np.float64)
+        if n > 20:
+            bad = rng.choice(n, n // 10, replace=False)
+            pts[bad] = np.stack([rng.uniform(0, 640, len(bad)), rng.uniform(0, 480, len(bad))], 1)
+        F = _fundamental_of(Kd, R, t)
+        if p % 7 == 3:
+            F = rng.normal(size=(3, 3)).astype(np.float32)  # not a fundamental matrix at all
+        if p % 11 == 5:
+            F = np.zeros((3, 3), np.float32)                 # every singular value vanishes: the completion path
+        Fs.append(F)
+        pts_l.append(pts)
+        ref_l.append(ref)
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pts, ref = np.concatenate(pts_l), np.concatenate(ref_l)
+    R, t, good = ransac.recover_pose_batch(np.stack(Fs), K, pts, ref, start)
+    n_right = 0
+    for p, n in enumerate(sizes):
+        oR, ot, og = oracle.recover_pose_fundamental(Fs[p], K, pts_l[p], ref_l[p])
+        assert np.array_equal(R[p], oR, equal_nan=True) and np.array_equal(t[p], ot, equal_nan=True), p
+        assert good[p] == og, p
+        n_right += og > 0.7 * n
+    assert n_right > len(sizes) // 2
+    xyz = ransac.triangulate_batch(K, R, t, pts, ref, start)
+    for p, n in enumerate(sizes):
+        o = oracle.triangulate_initial(K, R[p], t[p], pts_l[p], ref_l[p])
+        assert np.array_equal(xyz[start[p]:start[p + 1]], o, equal_nan=True), p
+    # the building blocks, against the oracle's front ends
+    P1 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = np.hstack([R[11], t[11][:, None]])
+    q = oracle.triangulate_points(P1, P2, ref_l[11][:5], pts_l[11][:5])
+    assert np.isfinite(q).all()
+
+
 def test_best_descriptor_batch_bit_exact(oracle, matcher):
     """MapPoint::computeBestDescriptor (map_point.cpp:109-166) for a batch of observation sets."""
     rng = np.random.default_rng(71)
