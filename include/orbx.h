@@ -326,6 +326,57 @@ orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream);
 orbx_status orbx_matcher_set_stream(orbx_matcher* h, void* hip_stream);
 orbx_status orbx_ransac_set_stream(orbx_ransac* h, void* hip_stream);
 
+/* ---- sequence input (callers' side of the extraction path) ---------------------------------------------------- */
+
+typedef struct orbx_sequence orbx_sequence;
+typedef struct orbx_feeder orbx_feeder;
+
+/* Replaces TUMRGBDCamera::setupCameraStream (src/geometry/rgbd_camera.cpp:225-252): reads dataset_dir + "assoc.txt",
+   one `time rgb_file time depth_file` per non-empty line; the first time stamp of a line is kept.  An empty list is
+   an error (the reference asserts). */
+orbx_status orbx_sequence_open(const char* dataset_dir, orbx_sequence** out);
+void orbx_sequence_close(orbx_sequence* seq);
+int orbx_sequence_length(const orbx_sequence* seq);
+/* The strings stay valid until orbx_sequence_close.  Any of the three outputs may be NULL. */
+orbx_status orbx_sequence_entry(const orbx_sequence* seq, int index, double* time_stamp, const char** rgb_file,
+                                const char** depth_file);
+
+/* What cv::imread returns for a PNG under the two flag values the reference uses
+   (include/orb_slam/geometry/rgbd_camera.h:211-213: CV_LOAD_IMAGE_UNCHANGED for the colour image; :224: the default
+   IMREAD_COLOR for the depth image).  UNCHANGED: channels in BGR(A) order, 8- or 16-bit samples as stored (host byte
+   order), gray+alpha expanded to four channels.  COLOR: always 3 x 8 bit, BGR; 16-bit samples keep their high byte,
+   alpha is dropped, gray is replicated.  Non-interlaced PNGs of bit depth 8 or 16; tRNS chunks are ignored.
+   With out == NULL only the geometry is returned. */
+enum { ORBX_IMREAD_UNCHANGED = -1, ORBX_IMREAD_COLOR = 1 };
+orbx_status orbx_png_decode(const uint8_t* file, size_t size, int mode, uint8_t* out, size_t out_capacity, int* width,
+                            int* height, int* channels, int* bytes_per_sample);
+orbx_status orbx_png_read(const char* path, int mode, uint8_t* out, size_t out_capacity, int* width, int* height,
+                          int* channels, int* bytes_per_sample);
+/* The depth scaling of TUMRGBDCamera::imageDepth (rgbd_camera.h:224-226): image.convertTo(CV_32F, depth_scale) on
+   the 8-bit image cv::imread returned; depth_scale is 255 * 0.0002 for TUM (rgbd_camera.cpp:212). */
+orbx_status orbx_depth_to_float(const uint8_t* bgr8, size_t n_values, float depth_scale, float* out);
+
+/* Keeps batches of frames flowing into HBM while the caller processes the previous batch.  No counterpart in the
+   reference (it reads one image per tracker step); this is what feeds orbx_extract_batch.  n_slots batches of
+   `batch` frames (width x height x channels bytes each) exist on the device; with 3 slots one is being processed,
+   one is on the bus, one is being decoded.  n_threads decode PNGs. */
+orbx_status orbx_feeder_create(int device, int width, int height, int channels, int batch, int n_slots, int n_threads,
+                               orbx_feeder** out);
+void orbx_feeder_destroy(orbx_feeder* f);
+/* Frames first .. first + count - 1 of the sequence's colour images (decoded as IMREAD_UNCHANGED; every image must
+   have the feeder's geometry).  Starting a job ends the previous one. */
+orbx_status orbx_feeder_start_sequence(orbx_feeder* f, const orbx_sequence* seq, int first, int count);
+/* `count` decoded frames already in host memory, frame i at frames + i * frame_stride.  The range is page-locked
+   for the duration of the job unless already_pinned says the caller has done so; uploads go straight from it. */
+orbx_status orbx_feeder_start_memory(orbx_feeder* f, const uint8_t* frames, size_t frame_stride, int count,
+                                     int already_pinned);
+/* Hands out the next batch in order: *d_frames (device memory, n_frames frames back to back), n_frames == 0 at the
+   end of the job.  The batch handed out by the previous call is recycled.  With a consumer stream the call does
+   not block on the GPU: the stream is made to wait for the upload, and the recycled batch is not overwritten
+   before the work queued on that stream so far has finished.  With consumer_stream == NULL the call waits for the
+   upload on the host, and the caller must have finished with the previous batch. */
+orbx_status orbx_feeder_next(orbx_feeder* f, void* consumer_stream, const uint8_t** d_frames, int* n_frames);
+
 #ifdef __cplusplus
 }
 #endif

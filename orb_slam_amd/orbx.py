@@ -28,6 +28,9 @@ SYMBOLS = [
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
     "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_recover_pose_batch", "orbx_triangulate_batch",
+    "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
+    "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
+    "orbx_feeder_start_memory", "orbx_feeder_next",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -566,3 +569,100 @@ class Ransac:
         n = lib().orbx_ransac_last_timings(self._h, _p(ms), 5)
         names = ["normalize", "solve", "score_f", "score_h", "select"]
         return dict(zip(names[:n], ms[:n].tolist()))
+
+
+IMREAD_UNCHANGED, IMREAD_COLOR = -1, 1
+
+
+def png_decode(data, mode=IMREAD_UNCHANGED):
+    """cv::imread's result for PNG bytes: (h, w[, c]) uint8 or uint16, channels in BGR(A) order."""
+    buf = np.frombuffer(data, np.uint8)
+    w, h, ch, bps = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _check(lib().orbx_png_decode(_p(buf), C.c_size_t(len(buf)), mode, None, C.c_size_t(0), C.byref(w), C.byref(h),
+                                 C.byref(ch), C.byref(bps)), "orbx_png_decode")
+    out = np.zeros(h.value * w.value * ch.value * bps.value, np.uint8)
+    _check(lib().orbx_png_decode(_p(buf), C.c_size_t(len(buf)), mode, _p(out), C.c_size_t(len(out)), None, None, None,
+                                 None), "orbx_png_decode")
+    arr = out.view(np.uint16) if bps.value == 2 else out
+    return arr.reshape(h.value, w.value, ch.value) if ch.value > 1 else arr.reshape(h.value, w.value)
+
+
+def png_read(path, mode=IMREAD_UNCHANGED):
+    with open(path, "rb") as f:
+        return png_decode(f.read(), mode)
+
+
+def depth_to_float(bgr8, depth_scale=np.float32(255 * 0.0002)):
+    src = np.ascontiguousarray(bgr8, np.uint8)
+    out = np.zeros(src.shape, np.float32)
+    _check(lib().orbx_depth_to_float(_p(src), C.c_size_t(src.size), C.c_float(depth_scale), _p(out)),
+           "orbx_depth_to_float")
+    return out
+
+
+class Sequence:
+    """TUM association list (TUMRGBDCamera::setupCameraStream of the reference)."""
+
+    def __init__(self, dataset_dir):
+        self._h = C.c_void_p()
+        self.dir = dataset_dir
+        _check(lib().orbx_sequence_open(dataset_dir.encode(), C.byref(self._h)), "orbx_sequence_open")
+
+    def __len__(self):
+        return lib().orbx_sequence_length(self._h)
+
+    def entry(self, i):
+        t, rgb, depth = C.c_double(), C.c_char_p(), C.c_char_p()
+        _check(lib().orbx_sequence_entry(self._h, i, C.byref(t), C.byref(rgb), C.byref(depth)), "orbx_sequence_entry")
+        return t.value, rgb.value.decode(), depth.value.decode()
+
+    def close(self):
+        if self._h:
+            lib().orbx_sequence_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Feeder:
+    """Batches of frames uploaded ahead of the consumer (orbx_feeder)."""
+
+    def __init__(self, width, height, channels, batch, n_slots=3, n_threads=8, device=0):
+        self._h = C.c_void_p()
+        self.frame_bytes = width * height * channels
+        _check(lib().orbx_feeder_create(device, width, height, channels, batch, n_slots, n_threads,
+                                        C.byref(self._h)), "orbx_feeder_create")
+
+    def start_sequence(self, seq, first, count):
+        self._keep = seq
+        _check(lib().orbx_feeder_start_sequence(self._h, seq._h, first, count), "orbx_feeder_start_sequence")
+
+    def start_memory(self, frames, already_pinned=False):
+        """frames: C-contiguous uint8 array (n, ...) of decoded frames; must stay alive during the job."""
+        self._keep = frames
+        n = frames.shape[0]
+        stride = frames.strides[0]
+        _check(lib().orbx_feeder_start_memory(self._h, C.c_void_p(frames.ctypes.data), C.c_size_t(stride), n,
+                                              int(already_pinned)), "orbx_feeder_start_memory")
+
+    def next(self, stream_ptr=None):
+        """-> (device pointer, frames); frames == 0 at the end of the job."""
+        d, n = C.c_void_p(), C.c_int()
+        _check(lib().orbx_feeder_next(self._h, C.c_void_p(stream_ptr) if stream_ptr else None, C.byref(d),
+                                      C.byref(n)), "orbx_feeder_next")
+        return d.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().orbx_feeder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
