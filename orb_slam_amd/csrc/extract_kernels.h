@@ -272,6 +272,7 @@ constexpr int kFPitch = 80;              // LDS bytes per staged row: 64 + 2*4 h
 constexpr int kFRows = kTileH + 8;
 constexpr int kSW = kTileW + 2, kSH = kTileH + 2;
 constexpr int kFGroups = 18;             // staged dwords per row that can hold a scored pixel (66 columns + alignment)
+constexpr int kQCols = 4 * kFGroups;     // columns a queue entry can name
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
                                                   int* __restrict__ chunk_counts, int words_per_chunk) {
     __shared__ __align__(16) unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
-    __shared__ unsigned short queue[kSW * kSH];
+    __shared__ unsigned short queue[kQCols * kSH];
     __shared__ unsigned s_mask[2 * kTileH];
     __shared__ unsigned s_sc8[2 * kTileH];
     __shared__ int q_count;
@@ -345,28 +346,26 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         const int item = min(base + tid, n1 - 1);
         const int r = item / kFGroups, gq = item - r * kFGroups;
         const int y = ys + r;
-        const int xg = tl.x0 - 4 - off + 4 * gq;          // level x of byte 0 of this dword
         const unsigned* tr = t32 + (y - tl.y0 + 4) * (kFPitch / 4) + gq;
         const unsigned C = tr[0], Lw = tr[-1], Rw = tr[1];
         const unsigned P0 = tr[3 * (kFPitch / 4)], P8 = tr[-3 * (kFPitch / 4)];
         const unsigned P4 = __builtin_amdgcn_alignbyte(Rw, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
-        // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12): a pixel without two
-        // adjacent compass points on the same side of the threshold band cannot be a corner
+        // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12), one of {0, 8} and one
+        // of {4, 12}: a corner needs min(max(p0, p8), max(p4, p12)) above the band or max(min(p0, p8), min(p4, p12))
+        // below it.  Both sides fold into ONE compare per pixel, so the scalar unit (one per CU, shared by the four
+        // SIMDs) only counts bits.  Lanes past the end carry a threshold nothing reaches; columns outside the scored
+        // range are dropped when the queue is read (phase 2).
+        const int thr = base + tid < n1 ? threshold : 1024;
         unsigned long long pass[4];
         int total = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int x = xg + j;
-            const bool valid = base + tid < n1 && x >= xs && x < xe;
             const int v = (int)((C >> (8 * j)) & 255u);
-            const int hi = v + threshold, lw = v - threshold;
             const int p0 = (int)((P0 >> (8 * j)) & 255u), p4 = (int)((P4 >> (8 * j)) & 255u);
             const int p8 = (int)((P8 >> (8 * j)) & 255u), p12 = (int)((P12 >> (8 * j)) & 255u);
-            const unsigned long long b0 = __ballot(p0 > hi), b4 = __ballot(p4 > hi), b8 = __ballot(p8 > hi),
-                                     b12 = __ballot(p12 > hi);
-            const unsigned long long d0 = __ballot(p0 < lw), d4 = __ballot(p4 < lw), d8 = __ballot(p8 < lw),
-                                     d12 = __ballot(p12 < lw);
-            pass[j] = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) & __ballot(valid);
+            const int up = min(max(p0, p8), max(p4, p12)) - v;
+            const int dn = v - max(min(p0, p8), min(p4, p12));
+            pass[j] = __ballot(max(up, dn) > thr);
             total += __popcll(pass[j]);
         }
         if (total == 0) continue;
@@ -374,11 +373,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         if (lane == 0) qb = atomicAdd(&q_count, total);
         qb = __builtin_amdgcn_readfirstlane(qb);
         const unsigned long long below = (1ull << lane) - 1ull;
+        const int code = r * kQCols + 4 * gq;  // (row of the ring-grown tile, staged column)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if ((pass[j] >> lane) & 1ull)
-                queue[qb + __popcll(pass[j] & below)] =
-                    (unsigned short)((y - tl.y0 + 1) * kSW + (xg + j - tl.x0 + 1));
+            if ((pass[j] >> lane) & 1ull) queue[qb + __popcll(pass[j] & below)] = (unsigned short)(code + j);
             qb += __popcll(pass[j]);
         }
     }
@@ -386,8 +384,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     // phase 2: cornerScore of the queued pixels: max(threshold, best arc-of-9 minimum of |v - p|) - 1
     const int nq = q_count;
     for (int q = tid; q < nq; q += 256) {
-        const int pos = queue[q];
-        const int r = pos / kSW, c = pos - r * kSW;
+        const int code = queue[q];
+        const int rr = code / kQCols;
+        const int x = tl.x0 - 4 - off + (code - rr * kQCols);  // level x of the queued pixel
+        if (x < xs || x >= xe) {
+            queue[q] = 0xffffu;
+            continue;
+        }
+        const int r = ys + rr - tl.y0 + 1, c = x - tl.x0 + 1;   // position in the ring-grown score tile
+        const int pos = r * kSW + c;
+        queue[q] = (unsigned short)pos;
         const uint8_t* ctr = t + (r + 3) * kFPitch + c + 3 + off;
         const int v = ctr[0];
         int d[16], m2[16], m4[16], x2[16], x4[16];
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     // phase 3: suppression and border rule for the queued corners of the tile proper; bits gathered per tile row
     for (int q = tid; q < nq; q += 256) {
         const int pos = queue[q];
+        if (pos == 0xffff) continue;
         const int c = st[pos];
         const int r = pos / kSW - 1, cc = pos - (r + 1) * kSW - 1;
         bool kp = false;
