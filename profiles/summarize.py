@@ -3,6 +3,7 @@
 
   summarize.py stats <run_kernel_stats.csv> <out.csv>        keeps the library's kernels, adds per-launch averages
   summarize.py pmc <fetch counter_collection.csv> <write counter_collection.csv> <frames_per_launch> <out.json>
+  summarize.py sq <counter_collection.csv> <out.json>        per-launch averages of whatever SQ_* counters the pass held
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-byte
 requests as 64 bytes, so wide coalesced reads show half their bytes: `traffic_bytes` = 2 x FETCH + WRITE.  For
@@ -20,7 +21,26 @@ def short(name):
     return name.split("::")[-1].split("<")[0]
 
 
+def sq_summary(path, out_path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        if ("orbx" in k or "anonymous namespace" in k) and "at::" not in k:
+            agg[short(k)][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[short(k)].add(r["Dispatch_Id"])
+    out = collections.OrderedDict()
+    for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", 0) / max(len(launches[k]), 1)):
+        n = max(len(launches[k]), 1)
+        out[k] = collections.OrderedDict(launches=n)
+        for c in sorted(agg[k]):
+            out[k][c + "_per_launch"] = round(agg[k][c] / n, 1)
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
 def main():
+    if sys.argv[1] == "sq":
+        return sq_summary(sys.argv[2], sys.argv[3])
     if sys.argv[1] == "stats":
         rows = list(csv.DictReader(open(sys.argv[2])))
         with open(sys.argv[3], "w", newline="") as f:
