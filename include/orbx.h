@@ -228,6 +228,31 @@ orbx_status orbx_match_epipolar(orbx_matcher* h, const orbx_keypoint* keypoints,
                                 const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
                                 int check_orientation, orbx_match* matches, int* count);
 
+/* Many frame pairs per call for the two matchers over vocabulary nodes: one workgroup per pair, so the key frames a
+   local-mapping step compares (src/local_mapping/local_mapper.cpp:277,462) are matched side by side.  A pair holds
+   exactly the arguments of the single-pair entry points.  matches: pair p writes from matches + (sum of n of the
+   earlier pairs), at most n of them; counts[p] = how many. */
+typedef struct orbx_bow_pair {
+    const orbx_keypoint* keypoints; int n; const uint8_t* descriptors;
+    const orbx_keypoint* ref_keypoints; int n_ref; const uint8_t* ref_descriptors;
+    const uint8_t* ref_has_point;
+    const uint32_t* node_ids; const int32_t* node_start; const int32_t* node_items; int n_nodes;
+    const uint32_t* ref_node_ids; const int32_t* ref_node_start; const int32_t* ref_node_items; int n_ref_nodes;
+} orbx_bow_pair;
+typedef struct orbx_epipolar_pair {
+    const orbx_keypoint* keypoints; int n; const uint8_t* descriptors;
+    const orbx_keypoint* ref_keypoints; int n_ref; const uint8_t* ref_descriptors;
+    const uint8_t* has_point; const uint8_t* ref_has_point;
+    const float* fundamental;
+    const uint32_t* node_ids; const int32_t* node_start; const int32_t* node_items; int n_nodes;
+    const uint32_t* ref_node_ids; const int32_t* ref_node_start; const int32_t* ref_node_items; int n_ref_nodes;
+} orbx_epipolar_pair;
+orbx_status orbx_match_bow_batch(orbx_matcher* h, const orbx_bow_pair* pairs, int n_pairs, int low_threshold,
+                                 float nn_ratio, int check_orientation, orbx_match* matches, int* counts);
+orbx_status orbx_match_epipolar_batch(orbx_matcher* h, const orbx_epipolar_pair* pairs, int n_pairs,
+                                      const float* scale_sigmas, int n_levels, int low_threshold,
+                                      int check_orientation, orbx_match* matches, int* counts);
+
 /* Replaces the candidate search of ORBMatcher::fuse (orb_matcher.cpp:806-867) for the points that passed the
    caller's own tests (:808-814: not bad, not yet observed in the key frame, KeyFrame::isInCameraViewLocal, whose
    projection and predicted level arrive in proj_xy / pred_level).  best_index[p] = the key frame's feature with the

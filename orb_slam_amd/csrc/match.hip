@@ -1109,7 +1109,8 @@ struct BowArgs {
     int32_t* pushes;       // scratch [2 * n_jobs]
 };
 
-__global__ __launch_bounds__(64) void k_bow_match(BowArgs A) {
+__global__ __launch_bounds__(64) void k_bow_match(const BowArgs* __restrict__ args) {
+    const BowArgs A = args[blockIdx.x];  // one frame pair per workgroup
     extern __shared__ int32_t s_matched[];  // [n]
     __shared__ int32_t s_idx[64];
     __shared__ int32_t s_dist[64];
@@ -1268,7 +1269,8 @@ struct EpiArgs {
     int32_t* pushes;           // scratch [2 * n]
 };
 
-__global__ __launch_bounds__(64) void k_epipolar_match(EpiArgs A) {
+__global__ __launch_bounds__(64) void k_epipolar_match(const EpiArgs* __restrict__ args) {
+    const EpiArgs A = args[blockIdx.x];  // one key-frame pair per workgroup
     extern __shared__ int32_t s_mem[];
     int32_t* s_matched = s_mem;                            // [n]
     unsigned short* s_d0 = (unsigned short*)(s_mem + A.n);  // [n]: d0, or 0xffff when the feature cannot match
@@ -1488,8 +1490,8 @@ struct orbx_matcher {
     DevBuf<orbx_keypoint> d_kp, d_refkp;
     DevBuf<int32_t> d_win_n, d_win_over;
     DevBuf<int2> d_win_list;
-    DevBuf<uint8_t> d_recs;
-    size_t fast_lds_attr = 0, lists_lds_attr = 0;
+    DevBuf<uint8_t> d_recs, d_args;
+    size_t fast_lds_attr = 0, lists_lds_attr = 0, bow_lds_attr = 0, epi_lds_attr = 0;
     std::vector<unsigned long long> h_best;
 };
 
@@ -1858,6 +1860,177 @@ orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, co
                           radius, nn_ratio, 0, matches, count);
 }
 
+// ---- back-end matchers over vocabulary nodes: many frame pairs per call -----------------------------------------
+}  // extern "C"
+
+namespace {
+
+bool valid_feature_vector(const uint32_t* ids, const int32_t* start, const int32_t* items, int nn, int limit) {
+    if (nn == 0) return true;
+    if (!ids || !start || !items || start[0] != 0) return false;
+    for (int i = 0; i < nn; i++) {
+        if (start[i + 1] < start[i]) return false;
+        if (i > 0 && !(ids[i - 1] < ids[i])) return false;
+    }
+    for (int i = 0; i < start[nn]; i++)
+        if (items[i] < 0 || items[i] >= limit) return false;
+    return true;
+}
+
+// Host-side concatenation of the per-pair arrays, uploaded with one copy per array.
+struct NodePack {
+    std::vector<orbx_keypoint> kp, refkp;
+    std::vector<uint8_t> desc, refdesc, flags;
+    std::vector<int32_t> items, jobs;
+    struct Off { size_t kp, refkp, flags, items, ref_items, jobs; int n_jobs; };
+    std::vector<Off> off;
+};
+
+template <typename T>
+void append(std::vector<T>& v, const T* p, size_t n) { if (n) v.insert(v.end(), p, p + n); }
+
+orbx_status upload_pack(orbx_matcher* h, const NodePack& P, size_t total_n, hipStream_t s) {
+    ORBX_TRY(h->d_kp.ensure(std::max<size_t>(P.kp.size(), 1)));
+    ORBX_TRY(h->d_refkp.ensure(std::max<size_t>(P.refkp.size(), 1)));
+    ORBX_TRY(h->d_q.ensure(std::max<size_t>(P.desc.size(), 32)));
+    ORBX_TRY(h->d_t.ensure(std::max<size_t>(P.refdesc.size(), 32)));
+    ORBX_TRY(h->d_flags.ensure(std::max<size_t>(P.flags.size(), 1)));
+    ORBX_TRY(h->d_items.ensure(std::max<size_t>(P.items.size(), 1)));
+    ORBX_TRY(h->d_ints.ensure(std::max<size_t>(P.jobs.size(), 1)));
+    ORBX_TRY(h->d_idx.ensure(total_n));
+    ORBX_TRY(h->d_dist.ensure(total_n));
+    ORBX_TRY(h->d_pushes.ensure(2 * total_n + 2 * P.jobs.size() + 2));
+    auto up = [&](void* d, const void* src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    ORBX_HIP(up(h->d_kp.p, P.kp.data(), P.kp.size() * sizeof(orbx_keypoint)));
+    ORBX_HIP(up(h->d_refkp.p, P.refkp.data(), P.refkp.size() * sizeof(orbx_keypoint)));
+    ORBX_HIP(up(h->d_q.p, P.desc.data(), P.desc.size()));
+    ORBX_HIP(up(h->d_t.p, P.refdesc.data(), P.refdesc.size()));
+    ORBX_HIP(up(h->d_flags.p, P.flags.data(), P.flags.size()));
+    ORBX_HIP(up(h->d_items.p, P.items.data(), P.items.size() * sizeof(int32_t)));
+    ORBX_HIP(up(h->d_ints.p, P.jobs.data(), P.jobs.size() * sizeof(int32_t)));
+    return ORBX_OK;
+}
+
+orbx_status raise_lds(const void* kernel, size_t bytes, size_t& current) {
+    if (bytes > 48 * 1024 && bytes > current) {
+        ORBX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        current = bytes;
+    }
+    return ORBX_OK;
+}
+
+// MatcherBase::createMatches (orb_matcher.h:81-93) per pair; pair p writes at matches + (features of earlier pairs).
+void create_matches_batch(const std::vector<int32_t>& matched, const std::vector<int32_t>& dists, const int* n_of,
+                          int n_pairs, orbx_match* matches, int* counts) {
+    size_t base = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        int c = 0;
+        for (int i = 0; i < n_of[p]; i++)
+            if (matched[base + i] > 0) matches[base + c++] = orbx_match{i, matched[base + i], -1, (float)dists[base + i]};
+        counts[p] = c;
+        base += n_of[p];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+orbx_status orbx_match_bow_batch(orbx_matcher* h, const orbx_bow_pair* pairs, int n_pairs, int low_threshold,
+                                 float nn_ratio, int check_orientation, orbx_match* matches, int* counts) {
+    if (!h || n_pairs < 0) return ORBX_BAD_ARG;
+    if (n_pairs == 0) return ORBX_OK;
+    if (!pairs || !counts) return ORBX_BAD_ARG;
+    NodePack P;
+    std::vector<int> n_of(n_pairs);
+    size_t total_n = 0;
+    int max_n = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        const orbx_bow_pair& q = pairs[p];
+        counts[p] = 0;
+        if (q.n < 0 || q.n_ref < 0 || q.n_nodes < 0 || q.n_ref_nodes < 0) return ORBX_BAD_ARG;
+        if (q.n > kMaxFeatures) return ORBX_CAPACITY;
+        const bool live = q.n > 0 && q.n_ref > 0 && q.n_nodes > 0 && q.n_ref_nodes > 0;
+        if (live && (!q.keypoints || !q.descriptors || !q.ref_keypoints || !q.ref_descriptors || !q.ref_has_point))
+            return ORBX_BAD_ARG;
+        if (live && (!valid_feature_vector(q.node_ids, q.node_start, q.node_items, q.n_nodes, q.n) ||
+                     !valid_feature_vector(q.ref_node_ids, q.ref_node_start, q.ref_node_items, q.n_ref_nodes, q.n_ref)))
+            return ORBX_BAD_ARG;
+        NodePack::Off o{P.kp.size(), P.refkp.size(), P.flags.size(), P.items.size(), 0, P.jobs.size(), 0};
+        n_of[p] = q.n;
+        if (live) {
+            // the reference's walk over the two std::maps with lower_bound jumps == intersection of the sorted id lists
+            for (int f = 0, rf = 0; f < q.n_nodes && rf < q.n_ref_nodes;) {
+                if (q.node_ids[f] == q.ref_node_ids[rf]) {
+                    for (int a = q.ref_node_start[rf]; a < q.ref_node_start[rf + 1]; a++) {
+                        P.jobs.push_back(q.ref_node_items[a]);
+                        P.jobs.push_back(q.node_start[f]);
+                        P.jobs.push_back(q.node_start[f + 1] - q.node_start[f]);
+                    }
+                    f++;
+                    rf++;
+                } else if (q.ref_node_ids[rf] < q.node_ids[f]) rf++;
+                else f++;
+            }
+            o.n_jobs = (int)((P.jobs.size() - o.jobs) / 3);
+            append(P.kp, q.keypoints, (size_t)q.n);
+            append(P.desc, q.descriptors, (size_t)q.n * 32);
+            append(P.refkp, q.ref_keypoints, (size_t)q.n_ref);
+            append(P.refdesc, q.ref_descriptors, (size_t)q.n_ref * 32);
+            append(P.flags, q.ref_has_point, (size_t)q.n_ref);
+            append(P.items, q.node_items, (size_t)q.node_start[q.n_nodes]);
+        } else {
+            // nothing can match: the kernel still clears the pair's outputs
+            P.kp.resize(P.kp.size() + q.n);
+            P.desc.resize(P.desc.size() + (size_t)q.n * 32);
+        }
+        P.off.push_back(o);
+        total_n += q.n;
+        max_n = std::max(max_n, q.n);
+    }
+    if (total_n == 0) return ORBX_OK;
+    if (!matches) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(upload_pack(h, P, total_n, s));
+    std::vector<BowArgs> args(n_pairs);
+    size_t out = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        const NodePack::Off& o = P.off[p];
+        BowArgs& A = args[p];
+        A.kps = h->d_kp.p + o.kp;
+        A.n = n_of[p];
+        A.desc = h->d_q.p + o.kp * 32;
+        A.ref_kps = h->d_refkp.p + o.refkp;
+        A.ref_desc = h->d_t.p + o.refkp * 32;
+        A.ref_flag = h->d_flags.p + o.flags;
+        A.jobs = h->d_ints.p + o.jobs;
+        A.n_jobs = o.n_jobs;
+        A.items = h->d_items.p + o.items;
+        A.low_threshold = low_threshold;
+        A.nn_ratio = nn_ratio;
+        A.check_orientation = check_orientation;
+        A.matched = h->d_idx.p + out;
+        A.dists = h->d_dist.p + out;
+        A.pushes = h->d_pushes.p + 2 * (o.jobs / 3);
+        out += n_of[p];
+    }
+    ORBX_TRY(h->d_args.ensure(sizeof(BowArgs) * (size_t)n_pairs));
+    ORBX_HIP(hipMemcpyAsync(h->d_args.p, args.data(), sizeof(BowArgs) * (size_t)n_pairs, hipMemcpyHostToDevice, s));
+    const size_t shmem = sizeof(int32_t) * (size_t)std::max(max_n, 1);
+    ORBX_TRY(raise_lds((const void*)k_bow_match, shmem, h->bow_lds_attr));
+    hipLaunchKernelGGL(k_bow_match, dim3(n_pairs), dim3(64), shmem, s, (const BowArgs*)h->d_args.p);
+    ORBX_HIP(hipGetLastError());
+    std::vector<int32_t> matched(total_n), dists(total_n);
+    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * total_n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * total_n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    create_matches_batch(matched, dists, n_of.data(), n_pairs, matches, counts);
+    return ORBX_OK;
+}
+
 orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int n, const uint8_t* descriptors,
                            const orbx_keypoint* ref_keypoints, int n_ref, const uint8_t* ref_descriptors,
                            const uint8_t* ref_has_point, const uint32_t* node_ids, const int32_t* node_start,
@@ -1865,90 +2038,127 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
                            const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes,
                            int low_threshold, float nn_ratio, int check_orientation, orbx_match* matches,
                            int* count) {
-    if (!h || !count || n < 0 || n_ref < 0 || n_nodes < 0 || n_ref_nodes < 0) return ORBX_BAD_ARG;
+    if (!h || !count) return ORBX_BAD_ARG;
     *count = 0;
-    if (n == 0 || n_ref == 0 || n_nodes == 0 || n_ref_nodes == 0) return ORBX_OK;
-    if (!keypoints || !descriptors || !ref_keypoints || !ref_descriptors || !ref_has_point || !node_ids ||
-        !node_start || !node_items || !ref_node_ids || !ref_node_start || !ref_node_items || !matches)
-        return ORBX_BAD_ARG;
-    if (n > kMaxFeatures) return ORBX_CAPACITY;
-    // validation of everything the kernel indexes with: ascending node ids, monotone offsets, indices in range
-    auto valid = [](const uint32_t* ids, const int32_t* start, const int32_t* items, int nn, int limit) {
-        if (start[0] != 0) return false;
-        for (int i = 0; i < nn; i++) {
-            if (start[i + 1] < start[i]) return false;
-            if (i > 0 && !(ids[i - 1] < ids[i])) return false;
-        }
-        for (int i = 0; i < start[nn]; i++)
-            if (items[i] < 0 || items[i] >= limit) return false;
-        return true;
-    };
-    if (!valid(node_ids, node_start, node_items, n_nodes, n) ||
-        !valid(ref_node_ids, ref_node_start, ref_node_items, n_ref_nodes, n_ref))
-        return ORBX_BAD_ARG;
-    // the reference's walk over the two std::maps with lower_bound jumps == intersection of the sorted id lists
-    std::vector<int32_t> jobs;
-    for (int f = 0, rf = 0; f < n_nodes && rf < n_ref_nodes;) {
-        if (node_ids[f] == ref_node_ids[rf]) {
-            for (int a = ref_node_start[rf]; a < ref_node_start[rf + 1]; a++) {
-                jobs.push_back(ref_node_items[a]);
-                jobs.push_back(node_start[f]);
-                jobs.push_back(node_start[f + 1] - node_start[f]);
+    const orbx_bow_pair q{keypoints, n, descriptors, ref_keypoints, n_ref, ref_descriptors, ref_has_point,
+                          node_ids, node_start, node_items, n_nodes, ref_node_ids, ref_node_start, ref_node_items,
+                          n_ref_nodes};
+    return orbx_match_bow_batch(h, &q, 1, low_threshold, nn_ratio, check_orientation, matches, count);
+}
+
+orbx_status orbx_match_epipolar_batch(orbx_matcher* h, const orbx_epipolar_pair* pairs, int n_pairs,
+                                      const float* scale_sigmas, int n_levels, int low_threshold,
+                                      int check_orientation, orbx_match* matches, int* counts) {
+    if (!h || n_pairs < 0) return ORBX_BAD_ARG;
+    if (n_pairs == 0) return ORBX_OK;
+    if (!pairs || !counts || !scale_sigmas || n_levels <= 0) return ORBX_BAD_ARG;
+    NodePack P;
+    std::vector<int> n_of(n_pairs);
+    size_t total_n = 0;
+    int max_n = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        const orbx_epipolar_pair& q = pairs[p];
+        counts[p] = 0;
+        if (q.n < 0 || q.n_ref < 0 || q.n_nodes < 0 || q.n_ref_nodes < 0) return ORBX_BAD_ARG;
+        if (q.n > kMaxFeatures) return ORBX_CAPACITY;
+        const bool live = q.n > 0 && q.n_ref > 0 && q.n_nodes > 0 && q.n_ref_nodes > 0;
+        if (live && (!q.keypoints || !q.descriptors || !q.ref_keypoints || !q.ref_descriptors || !q.has_point ||
+                     !q.ref_has_point || !q.fundamental))
+            return ORBX_BAD_ARG;
+        if (live && (!valid_feature_vector(q.node_ids, q.node_start, q.node_items, q.n_nodes, q.n) ||
+                     !valid_feature_vector(q.ref_node_ids, q.ref_node_start, q.ref_node_items, q.n_ref_nodes, q.n_ref)))
+            return ORBX_BAD_ARG;
+        NodePack::Off o{P.kp.size(), P.refkp.size(), P.flags.size(), P.items.size(), 0, P.jobs.size(), 0};
+        n_of[p] = q.n;
+        if (live) {
+            // common nodes in ascending order; where the reference would index out of range (row idx of the
+            // reference descriptors, matched[ref_idx]) the call is rejected
+            for (int f = 0, rf = 0; f < q.n_nodes && rf < q.n_ref_nodes;) {
+                if (q.node_ids[f] == q.ref_node_ids[rf]) {
+                    bool any_free = false;
+                    for (int b = q.node_start[f]; b < q.node_start[f + 1]; b++) {
+                        const int idx = q.node_items[b];
+                        if (q.has_point[idx]) continue;
+                        if (idx >= q.n_ref) return ORBX_BAD_ARG;
+                        any_free = true;
+                    }
+                    if (any_free)
+                        for (int a = q.ref_node_start[rf]; a < q.ref_node_start[rf + 1]; a++)
+                            if (q.ref_node_items[a] >= q.n) return ORBX_BAD_ARG;
+                    P.jobs.push_back(q.node_start[f]);
+                    P.jobs.push_back(q.node_start[f + 1] - q.node_start[f]);
+                    P.jobs.push_back(q.ref_node_start[rf]);
+                    P.jobs.push_back(q.ref_node_start[rf + 1] - q.ref_node_start[rf]);
+                    f++;
+                    rf++;
+                } else if (q.ref_node_ids[rf] < q.node_ids[f]) rf++;
+                else f++;
             }
-            f++;
-            rf++;
-        } else if (ref_node_ids[rf] < node_ids[f]) rf++;
-        else f++;
+            o.n_jobs = (int)((P.jobs.size() - o.jobs) / 4);
+            append(P.kp, q.keypoints, (size_t)q.n);
+            append(P.desc, q.descriptors, (size_t)q.n * 32);
+            append(P.refkp, q.ref_keypoints, (size_t)q.n_ref);
+            append(P.refdesc, q.ref_descriptors, (size_t)q.n_ref * 32);
+            append(P.flags, q.has_point, (size_t)q.n);
+            append(P.flags, q.ref_has_point, (size_t)q.n_ref);
+            append(P.items, q.node_items, (size_t)q.node_start[q.n_nodes]);
+            o.ref_items = P.items.size();
+            append(P.items, q.ref_node_items, (size_t)q.ref_node_start[q.n_ref_nodes]);
+        } else {
+            P.kp.resize(P.kp.size() + q.n);
+            P.desc.resize(P.desc.size() + (size_t)q.n * 32);
+            P.flags.resize(P.flags.size() + q.n, 1);  // "has a map point": the prologue then touches nothing else
+        }
+        P.off.push_back(o);
+        total_n += q.n;
+        max_n = std::max(max_n, q.n);
     }
-    const int n_jobs = (int)(jobs.size() / 3);
-    if (n_jobs == 0) return ORBX_OK;
+    if (total_n == 0) return ORBX_OK;
+    if (!matches) return ORBX_BAD_ARG;
     ORBX_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    const int n_items = node_start[n_nodes];
-    ORBX_TRY(h->d_kp.ensure(n));
-    ORBX_TRY(h->d_refkp.ensure(n_ref));
-    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
-    ORBX_TRY(h->d_t.ensure((size_t)n_ref * 32));
-    ORBX_TRY(h->d_flags.ensure(n_ref));
-    ORBX_TRY(h->d_items.ensure(std::max(n_items, 1)));
-    ORBX_TRY(h->d_ints.ensure((size_t)3 * n_jobs));
-    ORBX_TRY(h->d_idx.ensure(n));
-    ORBX_TRY(h->d_dist.ensure(n));
-    ORBX_TRY(h->d_pushes.ensure((size_t)2 * n_jobs + 2));
-    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, keypoints, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_refkp.p, ref_keypoints, sizeof(orbx_keypoint) * n_ref, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_q.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_t.p, ref_descriptors, (size_t)n_ref * 32, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_flags.p, ref_has_point, n_ref, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_items.p, node_items, sizeof(int32_t) * n_items, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_ints.p, jobs.data(), sizeof(int32_t) * jobs.size(), hipMemcpyHostToDevice, s));
-    BowArgs A;
-    A.kps = h->d_kp.p;
-    A.n = n;
-    A.desc = h->d_q.p;
-    A.ref_kps = h->d_refkp.p;
-    A.ref_desc = h->d_t.p;
-    A.ref_flag = h->d_flags.p;
-    A.jobs = h->d_ints.p;
-    A.n_jobs = n_jobs;
-    A.items = h->d_items.p;
-    A.low_threshold = low_threshold;
-    A.nn_ratio = nn_ratio;
-    A.check_orientation = check_orientation;
-    A.matched = h->d_idx.p;
-    A.dists = h->d_dist.p;
-    A.pushes = h->d_pushes.p;
-    hipLaunchKernelGGL(k_bow_match, dim3(1), dim3(64), sizeof(int32_t) * (size_t)n, s, A);
+    ORBX_TRY(upload_pack(h, P, total_n, s));
+    ORBX_TRY(h->d_f2.ensure(n_levels));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_sigmas, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    std::vector<EpiArgs> args(n_pairs);
+    size_t out = 0;
+    for (int p = 0; p < n_pairs; p++) {
+        const NodePack::Off& o = P.off[p];
+        const orbx_epipolar_pair& q = pairs[p];
+        EpiArgs& A = args[p];
+        A.kps = h->d_kp.p + o.kp;
+        A.n = n_of[p];
+        A.desc = h->d_q.p + o.kp * 32;
+        A.ref_kps = h->d_refkp.p + o.refkp;
+        A.n_ref = o.n_jobs ? q.n_ref : 0;
+        A.ref_desc = h->d_t.p + o.refkp * 32;
+        A.has_mp = h->d_flags.p + o.flags;
+        A.ref_has_mp = h->d_flags.p + o.flags + n_of[p];
+        for (int i = 0; i < 9; i++) A.F[i] = q.fundamental ? q.fundamental[i] : 0.f;
+        A.scale_sigmas = h->d_f2.p;
+        A.n_levels = n_levels;
+        A.jobs = h->d_ints.p + o.jobs;
+        A.n_jobs = o.n_jobs;
+        A.items = h->d_items.p + o.items;
+        A.ref_items = h->d_items.p + o.ref_items;
+        A.low_threshold = low_threshold;
+        A.check_orientation = check_orientation;
+        A.matched = h->d_idx.p + out;
+        A.dists = h->d_dist.p + out;
+        A.pushes = h->d_pushes.p + 2 * out;
+        out += n_of[p];
+    }
+    ORBX_TRY(h->d_args.ensure(sizeof(EpiArgs) * (size_t)n_pairs));
+    ORBX_HIP(hipMemcpyAsync(h->d_args.p, args.data(), sizeof(EpiArgs) * (size_t)n_pairs, hipMemcpyHostToDevice, s));
+    const size_t shmem = (sizeof(int32_t) + sizeof(unsigned short)) * (size_t)std::max(max_n, 1);
+    ORBX_TRY(raise_lds((const void*)k_epipolar_match, shmem, h->epi_lds_attr));
+    hipLaunchKernelGGL(k_epipolar_match, dim3(n_pairs), dim3(64), shmem, s, (const EpiArgs*)h->d_args.p);
     ORBX_HIP(hipGetLastError());
-    std::vector<int32_t> matched(n), dists(n);
-    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> matched(total_n), dists(total_n);
+    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * total_n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * total_n, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipStreamSynchronize(s));
-    // MatcherBase::createMatches (orb_matcher.h:81-93)
-    int c = 0;
-    for (int i = 0; i < n; i++)
-        if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
-    *count = c;
+    create_matches_batch(matched, dists, n_of.data(), n_pairs, matches, counts);
     return ORBX_OK;
 }
 
@@ -1960,114 +2170,13 @@ orbx_status orbx_match_epipolar(orbx_matcher* h, const orbx_keypoint* keypoints,
                                 const uint32_t* ref_node_ids, const int32_t* ref_node_start,
                                 const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
                                 int check_orientation, orbx_match* matches, int* count) {
-    if (!h || !count || n < 0 || n_ref < 0 || n_nodes < 0 || n_ref_nodes < 0) return ORBX_BAD_ARG;
+    if (!h || !count) return ORBX_BAD_ARG;
     *count = 0;
-    if (n == 0 || n_ref == 0 || n_nodes == 0 || n_ref_nodes == 0) return ORBX_OK;
-    if (!keypoints || !descriptors || !ref_keypoints || !ref_descriptors || !has_point || !ref_has_point ||
-        !fundamental || !scale_sigmas || n_levels <= 0 || !node_ids || !node_start || !node_items || !ref_node_ids ||
-        !ref_node_start || !ref_node_items || !matches)
-        return ORBX_BAD_ARG;
-    if (n > kMaxFeatures) return ORBX_CAPACITY;
-    auto valid = [](const uint32_t* ids, const int32_t* start, const int32_t* items, int nn, int limit) {
-        if (start[0] != 0) return false;
-        for (int i = 0; i < nn; i++) {
-            if (start[i + 1] < start[i]) return false;
-            if (i > 0 && !(ids[i - 1] < ids[i])) return false;
-        }
-        for (int i = 0; i < start[nn]; i++)
-            if (items[i] < 0 || items[i] >= limit) return false;
-        return true;
-    };
-    if (!valid(node_ids, node_start, node_items, n_nodes, n) ||
-        !valid(ref_node_ids, ref_node_start, ref_node_items, n_ref_nodes, n_ref))
-        return ORBX_BAD_ARG;
-    // common nodes in ascending order; where the reference would index out of range (row idx of the reference
-    // descriptors, matched[ref_idx]) the call is rejected
-    std::vector<int32_t> jobs;
-    for (int f = 0, rf = 0; f < n_nodes && rf < n_ref_nodes;) {
-        if (node_ids[f] == ref_node_ids[rf]) {
-            const int rlen = ref_node_start[rf + 1] - ref_node_start[rf];
-            bool any_free = false;
-            for (int b = node_start[f]; b < node_start[f + 1]; b++) {
-                const int idx = node_items[b];
-                if (has_point[idx]) continue;
-                if (idx >= n_ref) return ORBX_BAD_ARG;
-                any_free = true;
-            }
-            if (any_free)
-                for (int a = ref_node_start[rf]; a < ref_node_start[rf + 1]; a++)
-                    if (ref_node_items[a] >= n) return ORBX_BAD_ARG;
-            jobs.push_back(node_start[f]);
-            jobs.push_back(node_start[f + 1] - node_start[f]);
-            jobs.push_back(ref_node_start[rf]);
-            jobs.push_back(rlen);
-            f++;
-            rf++;
-        } else if (ref_node_ids[rf] < node_ids[f]) rf++;
-        else f++;
-    }
-    const int n_jobs = (int)(jobs.size() / 4);
-    if (n_jobs == 0) return ORBX_OK;
-    ORBX_HIP(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    const int n_items = node_start[n_nodes], n_ref_items = ref_node_start[n_ref_nodes];
-    ORBX_TRY(h->d_kp.ensure(n));
-    ORBX_TRY(h->d_refkp.ensure(n_ref));
-    ORBX_TRY(h->d_q.ensure((size_t)n * 32));
-    ORBX_TRY(h->d_t.ensure((size_t)n_ref * 32));
-    ORBX_TRY(h->d_flags.ensure((size_t)n + n_ref));
-    ORBX_TRY(h->d_items.ensure((size_t)std::max(n_items, 1) + std::max(n_ref_items, 1)));
-    ORBX_TRY(h->d_ints.ensure((size_t)4 * n_jobs));
-    ORBX_TRY(h->d_idx.ensure(n));
-    ORBX_TRY(h->d_dist.ensure(n));
-    ORBX_TRY(h->d_pushes.ensure((size_t)2 * n + 2));
-    ORBX_TRY(h->d_f2.ensure(n_levels));
-    int32_t* d_ref_items = h->d_items.p + std::max(n_items, 1);
-    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, keypoints, sizeof(orbx_keypoint) * n, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_refkp.p, ref_keypoints, sizeof(orbx_keypoint) * n_ref, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_q.p, descriptors, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_t.p, ref_descriptors, (size_t)n_ref * 32, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_flags.p, has_point, n, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_flags.p + n, ref_has_point, n_ref, hipMemcpyHostToDevice, s));
-    if (n_items > 0)
-        ORBX_HIP(hipMemcpyAsync(h->d_items.p, node_items, sizeof(int32_t) * n_items, hipMemcpyHostToDevice, s));
-    if (n_ref_items > 0)
-        ORBX_HIP(hipMemcpyAsync(d_ref_items, ref_node_items, sizeof(int32_t) * n_ref_items, hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_ints.p, jobs.data(), sizeof(int32_t) * jobs.size(), hipMemcpyHostToDevice, s));
-    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_sigmas, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
-    EpiArgs A;
-    A.kps = h->d_kp.p;
-    A.n = n;
-    A.desc = h->d_q.p;
-    A.ref_kps = h->d_refkp.p;
-    A.n_ref = n_ref;
-    A.ref_desc = h->d_t.p;
-    A.has_mp = h->d_flags.p;
-    A.ref_has_mp = h->d_flags.p + n;
-    for (int i = 0; i < 9; i++) A.F[i] = fundamental[i];
-    A.scale_sigmas = h->d_f2.p;
-    A.n_levels = n_levels;
-    A.jobs = h->d_ints.p;
-    A.n_jobs = n_jobs;
-    A.items = h->d_items.p;
-    A.ref_items = d_ref_items;
-    A.low_threshold = low_threshold;
-    A.check_orientation = check_orientation;
-    A.matched = h->d_idx.p;
-    A.dists = h->d_dist.p;
-    A.pushes = h->d_pushes.p;
-    const size_t shmem = sizeof(int32_t) * (size_t)n + sizeof(unsigned short) * (size_t)n;
-    hipLaunchKernelGGL(k_epipolar_match, dim3(1), dim3(64), shmem, s, A);
-    ORBX_HIP(hipGetLastError());
-    std::vector<int32_t> matched(n), dists(n);
-    ORBX_HIP(hipMemcpyAsync(matched.data(), h->d_idx.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    ORBX_HIP(hipMemcpyAsync(dists.data(), h->d_dist.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
-    ORBX_HIP(hipStreamSynchronize(s));
-    int c = 0;  // MatcherBase::createMatches (orb_matcher.h:81-93)
-    for (int i = 0; i < n; i++)
-        if (matched[i] > 0) matches[c++] = orbx_match{i, matched[i], -1, (float)dists[i]};
-    *count = c;
-    return ORBX_OK;
+    const orbx_epipolar_pair q{keypoints, n, descriptors, ref_keypoints, n_ref, ref_descriptors, has_point,
+                               ref_has_point, fundamental, node_ids, node_start, node_items, n_nodes, ref_node_ids,
+                               ref_node_start, ref_node_items, n_ref_nodes};
+    return orbx_match_epipolar_batch(h, &q, 1, scale_sigmas, n_levels, low_threshold, check_orientation, matches,
+                                     count);
 }
 
 orbx_status orbx_fuse_search(orbx_matcher* h, const orbx_grid* g, const int32_t* cell_start, const int32_t* cell_items,

@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_recover_pose_batch", "orbx_triangulate_batch",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_match_bow_batch", "orbx_match_epipolar_batch", "orbx_recover_pose_batch", "orbx_triangulate_batch",
     "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
@@ -244,6 +244,24 @@ class Extractor:
         return dict(zip(names[:n], ms[:n].tolist()))
 
 
+class BowPair(C.Structure):
+    _fields_ = [("keypoints", C.c_void_p), ("n", C.c_int), ("descriptors", C.c_void_p),
+                ("ref_keypoints", C.c_void_p), ("n_ref", C.c_int), ("ref_descriptors", C.c_void_p),
+                ("ref_has_point", C.c_void_p),
+                ("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("node_items", C.c_void_p), ("n_nodes", C.c_int),
+                ("ref_node_ids", C.c_void_p), ("ref_node_start", C.c_void_p), ("ref_node_items", C.c_void_p),
+                ("n_ref_nodes", C.c_int)]
+
+
+class EpipolarPair(C.Structure):
+    _fields_ = [("keypoints", C.c_void_p), ("n", C.c_int), ("descriptors", C.c_void_p),
+                ("ref_keypoints", C.c_void_p), ("n_ref", C.c_int), ("ref_descriptors", C.c_void_p),
+                ("has_point", C.c_void_p), ("ref_has_point", C.c_void_p), ("fundamental", C.c_void_p),
+                ("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("node_items", C.c_void_p), ("n_nodes", C.c_int),
+                ("ref_node_ids", C.c_void_p), ("ref_node_start", C.c_void_p), ("ref_node_items", C.c_void_p),
+                ("n_ref_nodes", C.c_int)]
+
+
 class Matcher:
     """Handle over orbx_matcher (ORBMatcher of the reference)."""
 
@@ -408,6 +426,62 @@ class Matcher:
                                          _p(nit), len(ni), _p(ri), _p(rs), _p(rit), len(ri), int(low_threshold),
                                          int(bool(check_orientation)), _p(out), C.byref(n)), "orbx_match_epipolar")
         return out[:n.value].copy()
+
+    def _nodes(self, nodes, keep):
+        arrs = (np.ascontiguousarray(nodes[0], np.uint32), np.ascontiguousarray(nodes[1], np.int32),
+                np.ascontiguousarray(nodes[2], np.int32))
+        keep.extend(arrs)
+        return arrs
+
+    def match_bow_batch(self, pairs, low_threshold=50, nn_ratio=0.6, check_orientation=True):
+        """pairs: list of (kps, desc, ref_kps, ref_desc, ref_has_point, nodes, ref_nodes) -> list of match arrays."""
+        keep, recs = [], (BowPair * max(len(pairs), 1))()
+        for i, (kps, desc, ref_kps, ref_desc, flags, nodes, ref_nodes) in enumerate(pairs):
+            kps = np.ascontiguousarray(kps, KP_DTYPE); ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+            desc = np.ascontiguousarray(desc, np.uint8); ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+            flags = np.ascontiguousarray(flags, np.uint8)
+            keep.extend([kps, ref_kps, desc, ref_desc, flags])
+            ni, ns, nit = self._nodes(nodes, keep)
+            ri, rs, rit = self._nodes(ref_nodes, keep)
+            recs[i] = BowPair(_p(kps), len(kps), _p(desc), _p(ref_kps), len(ref_kps), _p(ref_desc), _p(flags),
+                              _p(ni), _p(ns), _p(nit), len(ni), _p(ri), _p(rs), _p(rit), len(ri))
+        total = sum(len(p[0]) for p in pairs)
+        out = np.zeros(max(total, 1), MATCH_DTYPE)
+        counts = np.zeros(max(len(pairs), 1), np.int32)
+        _check(lib().orbx_match_bow_batch(self._h, recs, len(pairs), int(low_threshold), C.c_float(nn_ratio),
+                                          int(bool(check_orientation)), _p(out), _p(counts)), "orbx_match_bow_batch")
+        res, base = [], 0
+        for i, p in enumerate(pairs):
+            res.append(out[base:base + counts[i]].copy())
+            base += len(p[0])
+        return res
+
+    def match_epipolar_batch(self, pairs, scale_sigmas, low_threshold=50, check_orientation=True):
+        """pairs: list of (kps, desc, ref_kps, ref_desc, has_point, ref_has_point, F, nodes, ref_nodes)."""
+        keep, recs = [], (EpipolarPair * max(len(pairs), 1))()
+        sig = np.ascontiguousarray(scale_sigmas, np.float32)
+        for i, (kps, desc, ref_kps, ref_desc, has, ref_has, F, nodes, ref_nodes) in enumerate(pairs):
+            kps = np.ascontiguousarray(kps, KP_DTYPE); ref_kps = np.ascontiguousarray(ref_kps, KP_DTYPE)
+            desc = np.ascontiguousarray(desc, np.uint8); ref_desc = np.ascontiguousarray(ref_desc, np.uint8)
+            has = np.ascontiguousarray(has, np.uint8); ref_has = np.ascontiguousarray(ref_has, np.uint8)
+            F = np.ascontiguousarray(F, np.float32).reshape(9)
+            keep.extend([kps, ref_kps, desc, ref_desc, has, ref_has, F])
+            ni, ns, nit = self._nodes(nodes, keep)
+            ri, rs, rit = self._nodes(ref_nodes, keep)
+            recs[i] = EpipolarPair(_p(kps), len(kps), _p(desc), _p(ref_kps), len(ref_kps), _p(ref_desc), _p(has),
+                                   _p(ref_has), _p(F), _p(ni), _p(ns), _p(nit), len(ni), _p(ri), _p(rs), _p(rit),
+                                   len(ri))
+        total = sum(len(p[0]) for p in pairs)
+        out = np.zeros(max(total, 1), MATCH_DTYPE)
+        counts = np.zeros(max(len(pairs), 1), np.int32)
+        _check(lib().orbx_match_epipolar_batch(self._h, recs, len(pairs), _p(sig), len(sig), int(low_threshold),
+                                               int(bool(check_orientation)), _p(out), _p(counts)),
+               "orbx_match_epipolar_batch")
+        res, base = [], 0
+        for i, p in enumerate(pairs):
+            res.append(out[base:base + counts[i]].copy())
+            base += len(p[0])
+        return res
 
     def fuse_search(self, g, start, items, kps, desc, in_view, proj_xy, pred_level, pt_desc, scale_factors,
                     inv_scale_sigmas, radius_multiplier):

@@ -662,6 +662,45 @@ def test_pose_recovery_and_triangulation_bit_exact(oracle, ransac):
     assert np.isfinite(q).all()
 
 
+def test_backend_matchers_batched_equal_oracle(oracle, matcher, ex1000, test_images):
+    """orbx_match_bow_batch / orbx_match_epipolar_batch: key-frame pairs of different sizes side by side, each
+    equal to the oracle's result for that pair (and so to the single-pair entry points)."""
+    rng = np.random.default_rng(101)
+    _, _, _, sig, _ = ex1000.scale_tables()
+    F_tx = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    k_all, d_all = ex1000.compute(test_images[0], ex1000.detect(test_images[0]))
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    bow_pairs, epi_pairs = [], []
+    for n, n_nodes in ((len(k_all), 40), (700, 8), (64, 3), (0, 5), (333, 120), (900, 1), (500, 40)):
+        k0, d0 = k_all[:n], d_all[:n]
+        flips = (rng.uniform(size=(n, 256)) < rng.uniform(0.0, 0.25, (n, 1))).astype(np.uint8)
+        d1 = d0 ^ np.packbits(flips, axis=1) if n else d0
+        k1 = k0.copy()
+        k1["y"] += rng.normal(0, 1.5, n).astype(np.float32)
+        k1["angle"] = np.mod(k1["angle"] + rng.normal(0, 20, n), 360).astype(np.float32)
+        has = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+        ref_has = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+        nodes = _feature_vector(d0, rng, n_nodes, 0.1) if n else e
+        ref_nodes = _feature_vector(d1, rng, n_nodes, 0.1) if n else e
+        if n == 500:
+            ref_nodes = (ref_nodes[0] + 100000, ref_nodes[1], ref_nodes[2])   # no common node
+        bow_pairs.append((k0, d0, k1, d1, 1 - ref_has, nodes, ref_nodes))
+        epi_pairs.append((k0, d0, k1, d1, has, ref_has, F_tx, nodes, ref_nodes))
+    for low, ratio, orient in ((50, 0.6, True), (80, 0.9, False)):
+        got = matcher.match_bow_batch(bow_pairs, low, ratio, orient)
+        for p, g in zip(bow_pairs, got):
+            want = oracle.match_bow(*p, low, ratio, orient) if len(p[0]) else np.zeros(0, orbx.MATCH_DTYPE)
+            assert np.array_equal(g, want.astype(orbx.MATCH_DTYPE)), (len(p[0]), low)
+        got = matcher.match_epipolar_batch(epi_pairs, sig, low, orient)
+        for p, g in zip(epi_pairs, got):
+            k0, d0, k1, d1, has, ref_has, F, nodes, ref_nodes = p
+            want = (oracle.match_epipolar(k0, d0, k1, d1, has, ref_has, F, sig, nodes, ref_nodes, low, orient)
+                    if len(k0) else np.zeros(0, orbx.MATCH_DTYPE))
+            assert np.array_equal(g, want.astype(orbx.MATCH_DTYPE)), (len(k0), low)
+    assert sum(len(g) for g in got) > 300
+    assert matcher.match_bow_batch([]) == []
+
+
 def test_best_descriptor_batch_bit_exact(oracle, matcher):
     """MapPoint::computeBestDescriptor (map_point.cpp:109-166) for a batch of observation sets."""
     rng = np.random.default_rng(71)
