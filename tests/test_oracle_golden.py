@@ -67,8 +67,8 @@ def test_undistorted_bounds_reference_kat(oracle):
 
 def test_radius_matcher_reference_ranges(oracle, test_images):
     # src/tests/geometry/orb_matcher_tests.cpp:39-53.  The >= 4500 bound and the zero-duplicates property hold.
-    # The 750..800 window for the filtered count is NOT reproduced (1140 here): that count depends on descriptor
-    # bit statistics no reference fixture records, so the descriptor stage stays "parity unpinned".
+    # The 750..800 window for the filtered count is not met by the mean-absolute-difference distance this matcher
+    # computes today (1140 here); it is met when the distance is the Hamming distance: see the next test.
     p = _params(oracle, nfeatures=8000)
     r = []
     for img in test_images:
@@ -79,6 +79,25 @@ def test_radius_matcher_reference_ranges(oracle, test_images):
     f = oracle.filter_matches(m, len(r[0][1]))
     assert len(set(f["train"].tolist())) == len(f)
     assert 500 <= len(f) <= 1500
+
+
+def test_filtered_match_window_under_hamming_distance(oracle, test_images):
+    # src/tests/geometry/orb_matcher_tests.cpp:41 expects 750..800 matches after ORBMatcher::filterMatches, whose rule
+    # max(2 * min, 30) (orb_matcher.cpp:905) is the usual one for Hamming distances.  With the Hamming path of the
+    # reference, ORBMatcher::match(descriptors, ref_descriptors, matches, true) = cv::BFMatcher + filterMatches
+    # (orb_matcher.cpp:719-733), the oracle's descriptors of the two test images give 776: inside the window.  The
+    # window discriminates the descriptor stage: the same count is 665 with a blur of sigma 1.5 and 845 with 2.5
+    # (464 / 872 at sigma 1 / 3), so blur strength, steering and sampling pattern are consistent with what the
+    # reference's authors measured on OpenCV's own descriptors.
+    p = _params(oracle, nfeatures=8000)
+    d = []
+    for img in test_images:
+        k = oracle.detect(p, img)
+        d.append(oracle.compute(p, img, k)[1])
+    idx, dist = oracle.match_hamming(d[0], d[1])
+    f = oracle.filter_matches(oracle.matches_from(idx, dist), len(d[0]))
+    assert 750 <= len(f) <= 800
+    assert len(f) == 776
 
 
 def test_svd_null_vector_8x9(oracle):
