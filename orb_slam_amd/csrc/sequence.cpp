@@ -45,6 +45,7 @@ orbx_status png_header(const uint8_t* f, size_t size, PngHeader& h) {
     h.color_type = f[25];
     h.interlace = f[28];
     if (h.width <= 0 || h.height <= 0 || h.width > 65535 || h.height > 65535) return ORBX_BAD_ARG;
+    if ((size_t)h.width * h.height > ((size_t)1 << 27)) return ORBX_UNSUPPORTED;  // 128 Mpixel: bounds every buffer below
     const bool type_ok = h.color_type == 0 || h.color_type == 2 || h.color_type == 3 || h.color_type == 4 || h.color_type == 6;
     if (!type_ok || f[26] != 0 || f[27] != 0) return ORBX_BAD_ARG;
     if (h.interlace != 0) return ORBX_UNSUPPORTED;
