@@ -16,6 +16,9 @@ enum Stage { RT_NORMALIZE = 0, RT_SOLVE, RT_SCORE_F, RT_SCORE_H, RT_SELECT, RT_C
 struct orbx_ransac {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // the homography chain runs beside the fundamental chain (the reference uses two threads, Initializer.cpp:291-303)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<float> d_pts, d_ref, d_pn, d_rn, d_T, d_Fall, d_Hall, d_Hiall, d_sf, d_sh, d_F, d_H, d_scores;
     DevBuf<uint32_t> d_sets;
     DevBuf<uint8_t> d_inlf, d_inlh;
@@ -48,17 +51,23 @@ orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref,
     T.begin(RT_NORMALIZE, s);
     hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, h->d_pn.p, h->d_rn.p, h->d_T.p);
     T.end(RT_NORMALIZE, s);
-    T.begin(RT_SOLVE, s);
     const int hyp_blocks64 = (int)(((long long)pairs * iterations + 63) / 64);
-    hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
-                       iterations, pairs, h->d_Fall.p);
-    hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
-                       iterations, pairs, h->d_Hall.p, h->d_Hiall.p);
-    T.end(RT_SOLVE, s);
     // a 256-hypothesis workgroup spans at most kScorePairs pairs when iterations >= 86; below that, one launch
     // per group of pairs would be needed - the scorers then simply run pair by pair
     const bool flat = iterations >= 86;
     const int score_blocks = flat ? (int)(((long long)pairs * iterations + 255) / 256) : div_up(iterations, 256);
+    // F chain on the handle's stream, H chain on the side stream: neither fills the chip alone (3200 wavefronts for
+    // 1024 SIMDs at 1024 pairs x 200 iterations), together they leave fewer idle slots
+    hipStream_t sh = h->side_stream;
+    ORBX_HIP(hipEventRecord(h->ev_fork, s));
+    ORBX_HIP(hipStreamWaitEvent(sh, h->ev_fork, 0));
+    T.begin(RT_SOLVE, s);
+    hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
+                       iterations, pairs, h->d_Fall.p);
+    T.end(RT_SOLVE, s);
+    T.begin(RT_SCORE_H, sh);
+    hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, sh, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
+                       iterations, pairs, h->d_Hall.p, h->d_Hiall.p);
     T.begin(RT_SCORE_F, s);
     if (flat)
         hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, iterations,
@@ -69,17 +78,18 @@ orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref,
                                d_ref + (size_t)p * n * 2, n, h->d_Fall.p + (size_t)p * iterations * 9, iterations, 1,
                                sigma, h->d_sf.p + (size_t)p * iterations);
     T.end(RT_SCORE_F, s);
-    T.begin(RT_SCORE_H, s);
     if (flat)
-        hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, h->d_Hall.p,
+        hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points, d_ref, n, h->d_Hall.p,
                            h->d_Hiall.p, iterations, pairs, sigma, h->d_sh.p);
     else
         for (int p = 0; p < pairs; p++)
-            hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, s, d_points + (size_t)p * n * 2,
+            hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points + (size_t)p * n * 2,
                                d_ref + (size_t)p * n * 2, n, h->d_Hall.p + (size_t)p * iterations * 9,
                                h->d_Hiall.p + (size_t)p * iterations * 9, iterations, 1, sigma,
                                h->d_sh.p + (size_t)p * iterations);
-    T.end(RT_SCORE_H, s);
+    T.end(RT_SCORE_H, sh);
+    ORBX_HIP(hipEventRecord(h->ev_join, sh));
+    ORBX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     T.begin(RT_SELECT, s);
     hipLaunchKernelGGL(k_select, dim3(pairs, 2), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, h->d_Hall.p,
                        h->d_Hiall.p, h->d_sf.p, h->d_sh.p, iterations, sigma, d_F, d_H, d_inl_f, d_inl_h, d_scores,
@@ -121,6 +131,12 @@ orbx_status orbx_ransac_create(int device, orbx_ransac** out) {
         return ORBX_DEVICE;
     }
     h->stream = h->own_stream;
+    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        orbx_ransac_destroy(h);
+        return ORBX_DEVICE;
+    }
     orbx_status st = h->timer.init();
     if (st != ORBX_OK) {
         orbx_ransac_destroy(h);
@@ -142,6 +158,9 @@ void orbx_ransac_destroy(orbx_ransac* h) {
     h->d_t.release(); h->d_xyz.release(); h->d_K.release(); h->d_Fp.release(); h->d_pstart.release();
     h->d_good.release(); h->d_count.release();
     h->timer.destroy();
+    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

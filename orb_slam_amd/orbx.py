@@ -641,7 +641,7 @@ class Ransac:
     def last_timings(self):
         ms = np.zeros(5, np.float32)
         n = lib().orbx_ransac_last_timings(self._h, _p(ms), 5)
-        names = ["normalize", "solve", "score_f", "score_h", "select"]
+        names = ["normalize", "solve_f", "score_f", "solve_h+score_h_side_stream", "select"]
         return dict(zip(names[:n], ms[:n].tolist()))
 
 
