@@ -162,6 +162,34 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     ex.close()
 
 
+def test_extract_batch_ragged_inputs(oracle):
+    """Odd frame sizes, padded row strides, gray and colour input, and frames with no or almost no corners inside one
+    batch: every frame equals the oracle's detect + compute of that frame."""
+    import torch
+    for (w, h, ch) in ((333, 217, 1), (501, 363, 3), (64, 64, 3)):
+        frames = [synth_image(40 + i, w, h, ch) for i in range(3)]
+        flat = np.full_like(frames[0], 90)
+        one = flat.copy()
+        one[h // 2 - 4:h // 2 + 4, w // 2 - 4:w // 2 + 4] = 250          # a single bright square: a handful of corners
+        frames += [flat, one]
+        stride = (w * ch + 37) // 16 * 16 + 16                            # rows padded, not a multiple of the width
+        buf = np.zeros((len(frames), h, stride), np.uint8)
+        for f, img in enumerate(frames):
+            buf[f, :, :w * ch] = img.reshape(h, w * ch)
+        dev = torch.from_numpy(buf).cuda()
+        torch.cuda.synchronize()
+        ex = orbx.Extractor(n_key_points=500, level_pyramid=8, max_width=w, max_height=h, max_batch=len(frames))
+        p = oracle.orb_params(nfeatures=500)
+        kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), h * stride, w, h, stride, ch, 700)
+        for f, img in enumerate(frames):
+            ok_, od = oracle.compute(p, img, oracle.detect(p, img))
+            assert counts[f] == len(ok_), (w, h, ch, f)
+            assert np.array_equal(kps[f, :counts[f]], ok_.astype(orbx.KP_DTYPE)), (w, h, ch, f)
+            assert np.array_equal(desc[f, :counts[f]], od), (w, h, ch, f)
+        assert counts[3] == 0
+        ex.close()
+
+
 def test_match_hamming_bit_exact(oracle, matcher, ex1000, test_images):
     rng = np.random.default_rng(7)
     cases = []
