@@ -305,6 +305,34 @@ def test_ransac_per_hypothesis_bit_exact(oracle, ransac, utils_points):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (ci, name, np.abs(a - b).max())
 
 
+def test_ransac_degenerate_geometry_bit_exact(oracle, ransac):
+    """Rank-deficient eight-point systems (collinear points, four distinct points repeated, identical views, integer
+    lattices, a single point): the vanishing singular values take cv::SVDecomp's completion path, divisions by zero
+    produce inf / NaN - all of it bit for bit as the oracle, few iterations (the per-pair scoring path) included."""
+    rng = np.random.default_rng(29)
+    x = rng.uniform(0, 640, 60).astype(np.float32)
+    collinear = np.stack([x, 0.5 * x + 20], 1).astype(np.float32)
+    four = np.tile(np.array([[10, 10], [600, 20], [30, 400], [500, 450]], np.float32), (10, 1))
+    lattice = np.stack(np.meshgrid(np.arange(8) * 40.0, np.arange(8) * 30.0), -1).reshape(-1, 2).astype(np.float32)
+    generic = rng.uniform(0, 480, (50, 2)).astype(np.float32)
+    cases = [(collinear, collinear[::-1].copy()), (four, four + 1), (lattice, lattice), (lattice, lattice * 2 + 3),
+             (generic, generic), (np.full((12, 2), 7, np.float32), generic[:12]), (collinear, generic[:60] * 1e4)]
+    for ci, (pts, ref) in enumerate(cases):
+        for it in (5, 100):
+            sets = orbx.ransac_make_sets(len(pts), it, 200 + ci)
+            F, H, Hi, sf, sh = ransac.fh_all(pts, ref, sets, 1.0)
+            oF, oH, oHi, osf, osh = oracle.ransac_fh_all(pts, ref, sets, 1.0)
+            for name, a, b in (("F", F, oF), ("H", H, oH), ("Hinv", Hi, oHi), ("score_f", sf, osf), ("score_h", sh, osh)):
+                # a NaN is a NaN: x86 and gfx950 give their default NaNs different sign bits
+                nan = np.isnan(a)
+                assert np.array_equal(nan, np.isnan(b)), (ci, it, name)
+                assert np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan]), (ci, it, name)
+            r = ransac.fh(pts, ref, sets, 1.0)
+            o = oracle.ransac_fh(pts, ref, sets, 1.0)
+            assert np.array_equal(r["best_it"], o["best_it"]), (ci, it)
+            assert np.array_equal(r["inliers_f"], o["inliers_f"]) and np.array_equal(r["inliers_h"], o["inliers_h"])
+
+
 def test_ransac_result_identical(oracle, ransac, utils_points):
     rng = np.random.default_rng(22)
     cases = [_two_view(rng, 500, 150), _two_view(rng, 1200, 300, planar=True),
