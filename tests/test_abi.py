@@ -118,3 +118,19 @@ def test_retain_best_replay_matches_libstdcxx(oracle):
         a = orbx.selftest_retain_best(keys, npts)
         b = oracle.retain_best(keys, npts)
         assert np.array_equal(a, b), (len(keys), npts)
+
+
+def test_no_fallback_without_library_or_gpu(monkeypatch):
+    """The product path has no CPU fallback: a missing liborbx.so raises at the first use, and without a GPU the
+    extractor cannot be created."""
+    import torch
+    monkeypatch.setattr(orbx, "_lib", None)
+    monkeypatch.setattr(orbx, "LIB_PATH", orbx.LIB_PATH + ".absent")
+    with pytest.raises(ImportError):
+        orbx.lib()
+    monkeypatch.undo()
+    if not torch.cuda.is_available():
+        with pytest.raises(orbx.OrbxError):
+            orbx.Extractor(n_key_points=100, level_pyramid=2, max_width=64, max_height=64)
+        with pytest.raises(orbx.OrbxError):
+            orbx.Matcher()
