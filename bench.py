@@ -146,7 +146,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=792,
+                    help="frames per GPU per step (792 = one TUM fr1/xyz-length sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ransac-pairs", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=2, help="independent batches in flight per GPU")
@@ -275,6 +276,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same stage timings with one batch alone on the GPU (after the timed region, not part of `value`): with
+    # several batches in flight a kernel shares the CUs with the other batch's kernels and its own duration stretches
+    timed_stage_ms, timed_match_ms = stage_ms, match_ms
+    alone_avg = None
+    if len(pipes) > 1:
+        stage_ms, match_ms = {}, []
+        for _ in range(3):
+            pipes[0].step(True)
+        torch.cuda.synchronize()
+        alone_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+        alone_avg["match_window"] = float(np.mean([a.elapsed_time(b) for a, b in match_ms]))
+        stage_ms, match_ms = timed_stage_ms, timed_match_ms
+
     ex, d_nm = pipes[0].ex, pipes[0].d_nm
     stream = pipes[0].tstream.cuda_stream
     torch.cuda.set_stream(pipes[0].tstream)
@@ -286,17 +300,19 @@ def main():
     per_kernel, frame_bytes = algorithmic_bytes(NKP)
     stage_avg = {k: float(np.mean(v)) for k, v in stage_ms.items()}
     stage_avg["match_window"] = float(np.mean([a.elapsed_time(b) for a, b in match_ms]))
-    dom = max((k for k in stage_avg if k in per_kernel), key=lambda k: stage_avg[k])
+    # launches per stage: the pyramid stage is one launch per level above 0, every other stage is one kernel launch
+    launches = {k: (NLEVELS - 1 if k == "resize" else 1) for k in per_kernel}
+    dom = max((k for k in stage_avg if k in per_kernel), key=lambda k: stage_avg[k] / launches[k])
     achieved = per_kernel[dom] * B / (stage_avg[dom] * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs of this command)
     traffic = None
-    kernel_of = {"gray": "k_gray_level0", "resize": "k_resize_level4", "fast": "k_fast_nms", "emit": "k_emit",
+    kernel_of = {"gray": "k_gray_level0", "resize": "k_resize_strip", "fast": "k_fast_nms", "emit": "k_emit",
                  "harris": "k_harris_angle", "blur": "k_blur", "brief": "k_brief"}
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pmc = json.load(f).get(kernel_of[dom])
         if pmc and pmc.get("frames_per_launch") == B:
-            traffic = pmc["traffic_bytes"] * (NLEVELS - 1 if dom == "resize" else 1)
+            traffic = pmc["traffic_bytes"] * launches[dom]
     except (OSError, ValueError, KeyError):
         pass
     roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -304,6 +320,9 @@ def main():
                 "algorithmic_bytes_per_launch": per_kernel[dom] * B,
                 "stage_ms_per_batch": stage_avg, "algorithmic_bytes_per_frame": frame_bytes,
                 "device_ms_per_batch": float(sum(stage_avg.values()))}
+    if alone_avg:
+        roofline["stage_ms_per_batch_alone"] = alone_avg
+        roofline["frac_alone"] = per_kernel[dom] * B / (alone_avg[dom] * 1e-3) / 1e9 / 8000.0
 
     # RANSAC hypotheses/s (second half of the headline metric): 200 iterations x 2000 correspondences per pair
     ransac = None
@@ -361,7 +380,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "TUM-fr1-like monocular 640x480 BGR sequence (homography walk of the reference "
+            "config": {"workload": "TUM-fr1-like monocular 640x480 BGR sequence, one sequence per step (homography walk of the reference "
                                    "test image + noise), 1000 kp, 8 levels x1.2: per-frame extract (detect, "
                                    "undistort, 64x64 grid, compute) + windowed match (radius 15) to the previous frame",
                        "frames_per_gpu_per_step": B, "batches_in_flight": len(pipes), "mean_keypoints": mean_kp,

@@ -794,18 +794,37 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         fm.height = height;
         fm.edge = h->prm.edge_threshold;
         fm.patch_size = h->prm.patch_size;
-        const size_t shmem = sizeof(stdsel::Elem) * kSelectMaxCands +
-                             std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)),
-                                      sizeof(uint16_t) * 2 * (size_t)kSelectMaxCands);
+        // LDS of one workgroup: the selection elements of up to max_cands candidates, then the keypoint / cell area
+        // (which the stopper lists of the partitions alias).  A workgroup sized for kSelectMaxCands has a CU to
+        // itself; most frames have far fewer candidates, so a first launch with half a CU's LDS per workgroup (two
+        // frames per CU) takes every frame that fits it and marks the others (status 3) for a second, full-size launch.
+        auto select_lds = [&](int max_cands) {
+            return sizeof(stdsel::Elem) * (size_t)max_cands +
+                   std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)), sizeof(uint16_t) * 2 * (size_t)max_cands);
+        };
+        const size_t shmem = select_lds(kSelectMaxCands);
         if (!h->select_attr_set || shmem > h->select_attr_bytes) {
             ORBX_HIP(hipFuncSetAttribute((const void*)k_select_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             h->select_attr_set = true;
             h->select_attr_bytes = shmem;
         }
+        const long half_cu = 80 * 1024 - 512;  // half of the CU's 160 KB, less the kernel's static LDS and rounding
+        const long kp_area = (long)capacity * (long)(sizeof(orbx_keypoint) + sizeof(int));
+        const int small_cands = (int)((half_cu - kp_area) / (long)sizeof(stdsel::Elem)) / 64 * 64;
+        const bool two_tier = small_cands >= 2048 && small_cands < kSelectMaxCands && ncell_dev + 1 <= small_cands * 2;
         h->timer.begin(ST_SELECT, h->stream);
-        hipLaunchKernelGGL(k_select_frame, dim3(n_frames), dim3(64 * h->geom.nlevels), shmem, h->stream, h->d_cand.p,
-                           h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm, h->d_kp.p, capacity,
-                           h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p);
+        auto launch_select = [&](int max_cands, int pass) {
+            hipLaunchKernelGGL(k_select_frame, dim3(n_frames), dim3(64 * h->geom.nlevels), select_lds(max_cands),
+                               h->stream, h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm,
+                               h->d_kp.p, capacity, h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p,
+                               h->d_status.p, max_cands, pass);
+        };
+        if (two_tier) {
+            launch_select(small_cands, 0);
+            launch_select(kSelectMaxCands, 1);
+        } else {
+            launch_select(kSelectMaxCands, -1);
+        }
         h->timer.end(ST_SELECT, h->stream);
         ORBX_HIP(hipGetLastError());
         ORBX_TRY(run_describe_stage(h, n_frames));

@@ -274,6 +274,9 @@ constexpr int kSW = kTileW + 2, kSH = kTileH + 2;
 constexpr int kFGroups = 18;             // staged dwords per row that can hold a scored pixel (66 columns + alignment)
 constexpr int kQCols = 4 * kFGroups;     // columns a queue entry can name
 
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2v as_short2v(unsigned w) { return __builtin_bit_cast(short2v, w); }
+
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
                                                   MaskWord* __restrict__ mask, size_t atlas_bytes, Geom g,
@@ -356,17 +359,21 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         // SIMDs) only counts bits.  Lanes past the end carry a threshold nothing reaches; columns outside the scored
         // range are dropped when the queue is read (phase 2).
         const int thr = base + tid < n1 ? threshold : 1024;
+        // two pixels per instruction: even pixels of the dword in one pair of 16-bit halves, odd pixels in another
         unsigned long long pass[4];
         int total = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int v = (int)((C >> (8 * j)) & 255u);
-            const int p0 = (int)((P0 >> (8 * j)) & 255u), p4 = (int)((P4 >> (8 * j)) & 255u);
-            const int p8 = (int)((P8 >> (8 * j)) & 255u), p12 = (int)((P12 >> (8 * j)) & 255u);
-            const int up = min(max(p0, p8), max(p4, p12)) - v;
-            const int dn = v - max(min(p0, p8), min(p4, p12));
-            pass[j] = __ballot(max(up, dn) > thr);
-            total += __popcll(pass[j]);
+        for (int hsel = 0; hsel < 2; hsel++) {
+            const unsigned sel = hsel ? 0x0c030c01u : 0x0c020c00u;
+            const short2v v = as_short2v(__builtin_amdgcn_perm(0u, C, sel));
+            const short2v p0 = as_short2v(__builtin_amdgcn_perm(0u, P0, sel)), p4 = as_short2v(__builtin_amdgcn_perm(0u, P4, sel));
+            const short2v p8 = as_short2v(__builtin_amdgcn_perm(0u, P8, sel)), p12 = as_short2v(__builtin_amdgcn_perm(0u, P12, sel));
+            const short2v up = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)) - v;
+            const short2v dn = v - __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+            const short2v m = __builtin_elementwise_max(up, dn);
+            pass[hsel] = __ballot(m.x > (short)thr);
+            pass[hsel + 2] = __ballot(m.y > (short)thr);
+            total += __popcll(pass[hsel]) + __popcll(pass[hsel + 2]);
         }
         if (total == 0) continue;
         int qb = 0;
@@ -803,28 +810,33 @@ __device__ __forceinline__ int compact_ordered(orbx_keypoint* s_kp, int n, int l
 //   retainBest(2*quota) on the FAST score, retainBest(quota) on the Harris response (the level's wave replays
 //   libstdc++'s nth_element + partition, stdsel.h), keypoint assembly (size, angle, level-0 coordinates),
 //   Camera::undistortPoints, Frame::assignFeaturesToGrid (ordered filter + CSR cells), and the border filter of
-//   cv::ORB::compute.  status[frame]: 0 ok, 1 more keypoints than kp_cap, 2 more candidates than the LDS holds.
+//   cv::ORB::compute.  status[frame]: 0 ok, 1 more keypoints than kp_cap, 2 more candidates than the LDS holds
+//   (3 between the two launches: left to the full-size one).
 __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ cand, int cand_cap,
                                                         const int* __restrict__ level_counts,
                                                         const int* __restrict__ totals, Geom g, FrameModel fm,
                                                         orbx_keypoint* __restrict__ kps_out, int kp_cap,
                                                         int* __restrict__ kp_counts, int* __restrict__ cell_start,
-                                                        int* __restrict__ cell_items, int* __restrict__ status) {
+                                                        int* __restrict__ cell_items, int* __restrict__ status,
+                                                        int max_cands, int pass) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ int s_n[kMaxLevels], s_off[kMaxLevels], s_cnt;
-    stdsel::Elem* s_el = (stdsel::Elem*)s_raw;                                  // [kSelectMaxCands]
-    orbx_keypoint* s_kp = (orbx_keypoint*)(s_raw + sizeof(stdsel::Elem) * kSelectMaxCands);  // [kp_cap]
+    stdsel::Elem* s_el = (stdsel::Elem*)s_raw;                                  // [max_cands]
+    orbx_keypoint* s_kp = (orbx_keypoint*)(s_raw + sizeof(stdsel::Elem) * max_cands);  // [kp_cap]
     int* s_cell = (int*)(s_kp + kp_cap);                                         // [kp_cap]
     int* s_cells = (int*)s_raw;                                                  // [ncell + 1], aliases s_el later
     // stopper lists of the wave-parallel partitions; they alias s_kp / s_cell, which are idle during the selection
-    uint16_t* s_lp = (uint16_t*)s_kp;                                            // [kSelectMaxCands]
-    uint16_t* s_rp = s_lp + kSelectMaxCands;                                     // [kSelectMaxCands]
+    uint16_t* s_lp = (uint16_t*)s_kp;                                            // [max_cands]
+    uint16_t* s_rp = s_lp + max_cands;                                           // [max_cands]
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, lvl = tid >> 6;
     const Cand* cd = cand + (size_t)b * cand_cap;
     const int total = totals[b];
-    if (total > kSelectMaxCands || total > cand_cap) {
-        if (tid == 0) { status[b] = 2; kp_counts[b] = 0; }
+    // pass 0: the launch with the small LDS leaves frames that do not fit it to pass 1 (status 3); pass 1 takes only
+    // those; pass -1 is the single full-size launch
+    if (pass == 1 && status[b] != 3) return;
+    if (total > max_cands || total > cand_cap) {
+        if (tid == 0) { status[b] = (pass == 0 && total <= cand_cap) ? 3 : 2; kp_counts[b] = 0; }
         return;
     }
     int n = 0, off = 0;

@@ -524,8 +524,12 @@ __global__ __launch_bounds__(256) void k_score_f(const float* __restrict__ pts, 
     if (live) score_out[(size_t)sp.pair * iterations + sp.it] = (float)score;
 }
 
-// K12H: Initializer::checkHomographyScore (Initializer.cpp:501-585); fp32 with the double reciprocal of the
-// reference (`1.0 / (float expression)` narrowed to float).
+// K12H: Initializer::checkHomographyScore (Initializer.cpp:501-585); fp32.  The reference writes the reciprocal as
+// `1.0 / (float expression)` narrowed to float: a double division rounded twice.  The correctly rounded float
+// division used here gives the same bits for every input: 1/x of a 24-bit x lies at least 2^-49 (relative) away
+// from any midpoint between two floats (x * midpoint is an integer of at most 49 bits and never exactly a power of
+// two unless 1/x is exact), far more than the 2^-53 the first rounding can move it, so the second rounding never
+// changes side; zeros, infinities and out-of-range quotients behave alike in both forms.
 __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, const float* __restrict__ ref, int n,
                                                  const float* __restrict__ H_all, const float* __restrict__ Hinv_all,
                                                  int iterations, int pairs, double sigma,
@@ -551,13 +555,13 @@ __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, 
             for (int i = 0; i < cnt; i++) {
                 const float4 q = s_pt[sp.slot][i];
                 const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
-                const float w2in1inv = 1.0 / (i31 * u2 + i32 * v2 + i33);
+                const float w2in1inv = 1.0f / (i31 * u2 + i32 * v2 + i33);
                 const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
                 const float v2in1 = (i21 * u2 + i22 * v2 + i23) * w2in1inv;
                 const float sq1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
                 const float chi1 = sq1 * invSigmaSquare;
                 if (!(chi1 > th)) score += th - chi1;
-                const float w1in2inv = 1.0 / (h31 * u1 + h32 * v1 + h33);
+                const float w1in2inv = 1.0f / (h31 * u1 + h32 * v1 + h33);
                 const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
                 const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
                 const float sq2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);

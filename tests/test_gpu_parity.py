@@ -774,12 +774,12 @@ def test_best_descriptor_batch_bit_exact(oracle, matcher):
 
 
 def test_full_size_batches_are_consistent(oracle, ransac, test_images):
-    """The bench-sized batches (256 VGA frames; 1024 pairs x 200 iterations x 2000 correspondences): every copy of a
+    """The bench-sized batches (792 VGA frames; 1024 pairs x 200 iterations x 2000 correspondences): every copy of a
     repeated unit gives the unit's result, and the distinct units equal the oracle."""
     import torch
-    # extraction: 256 frames tiled from 4 distinct ones
+    # extraction: 792 frames tiled from 4 distinct ones
     distinct = [test_images[0], test_images[1], synth_image(91, 640, 480, 3), synth_image(92, 640, 480, 3)]
-    B, cap = 256, 1280
+    B, cap = 792, 1280
     dev = torch.from_numpy(np.stack([distinct[f % 4] for f in range(B)])).cuda()
     torch.cuda.synchronize()
     ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=B)
