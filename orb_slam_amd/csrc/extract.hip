@@ -774,7 +774,11 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     // (k_select_frame), so nothing crosses PCIe between detect and compute.  It covers frames whose candidates fit
     // its LDS; otherwise (status 2) the whole batch is redone by the host path below, which has no such limit.
     const int ncell_dev = h->has_grid ? h->grid.grid_cols * h->grid.grid_rows : 0;
-    if (h->device_select && capacity <= 4096 && ncell_dev + 1 <= kSelectMaxCands * 2) {
+    // the device path needs its selection elements and `capacity` keypoint slots in one CU's LDS (160 KB)
+    const size_t select_lds_full = sizeof(stdsel::Elem) * (size_t)kSelectMaxCands +
+                                   std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)),
+                                            sizeof(uint16_t) * 2 * (size_t)kSelectMaxCands);
+    if (h->device_select && select_lds_full <= 160 * 1024 - 512 && ncell_dev + 1 <= kSelectMaxCands * 2) {
         h->kp_cap = capacity;
         ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
         ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));

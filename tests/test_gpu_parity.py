@@ -162,6 +162,29 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     ex.close()
 
 
+def test_selection_launch_tiers(oracle, test_images):
+    """The selection kernel is launched with a small LDS footprint first and full-size for the frames left over; how
+    many candidates the small launch holds depends on the keypoint capacity.  Capacities on both sides of every
+    switch, with a frame without corners (always taken by the first launch) beside ~4000-candidate frames."""
+    import torch
+    frames = [test_images[0], np.full_like(test_images[0], 77), test_images[1], synth_image(61, 640, 480, 3)]
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(frames))
+    p = oracle.orb_params(nfeatures=1000)
+    ora = [oracle.compute(p, img, oracle.detect(p, img)) for img in frames]
+    # 1100/1280: every frame fits the first launch; 1700/2000: the textured frames need the second; 2300: one launch;
+    # 4096: more keypoint slots than the selection kernel can hold, the host selection takes over
+    for cap in (1100, 1280, 1700, 2000, 2300, 4096):
+        kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+        for f, (ok_, od) in enumerate(ora):
+            assert counts[f] == len(ok_), (cap, f)
+            assert np.array_equal(kps[f, :counts[f]], ok_.astype(orbx.KP_DTYPE)), (cap, f)
+            assert np.array_equal(desc[f, :counts[f]], od), (cap, f)
+        assert counts[1] == 0
+    ex.close()
+
+
 def test_extract_batch_ragged_inputs(oracle):
     """Odd frame sizes, padded row strides, gray and colour input, and frames with no or almost no corners inside one
     batch: every frame equals the oracle's detect + compute of that frame."""
