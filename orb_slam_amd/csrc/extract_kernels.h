@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
             const unsigned ab[4] = {__builtin_amdgcn_perm(B4, A4, 0x0c040c00u), __builtin_amdgcn_perm(B4, A4, 0x0c050c01u),
                                     __builtin_amdgcn_perm(B4, A4, 0x0c060c02u), __builtin_amdgcn_perm(B4, A4, 0x0c070c03u)};
 #pragma unroll
-            for (int j = 0; j < 4; j++) hh[j] = (ab[j] & 0xffffu) * (wgt[j] & 0xffffu) + (ab[j] >> 16) * (wgt[j] >> 16);
+            for (int j = 0; j < 4; j++) hh[j] = __umul24(ab[j] & 0xffffu, wgt[j] & 0xffffu) + __umul24(ab[j] >> 16, wgt[j] >> 16);
             s_h[wv][k][lane] = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));  // each sum <= 255 * 256
         }
     }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
         const unsigned bh[4] = {b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16};
         unsigned out = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) out |= ((wy0 * ah[j] + wy1 * bh[j] + (1u << 15)) >> 16) << (8 * j);
+        for (int j = 0; j < 4; j++) out |= ((__umul24(wy0, ah[j]) + __umul24(wy1, bh[j]) + (1u << 15)) >> 16) << (8 * j);
         uint8_t* d = fb + (size_t)(dst.y - border + ty) * aw + ax_begin + dc * 4;
         if (whole) *(unsigned*)d = out;
         else {
@@ -273,6 +273,15 @@ constexpr int kFRows = kTileH + 8;
 constexpr int kSW = kTileW + 2, kSH = kTileH + 2;
 constexpr int kFGroups = 18;             // staged dwords per row that can hold a scored pixel (66 columns + alignment)
 constexpr int kQCols = 4 * kFGroups;     // columns a queue entry can name
+
+// i / D for 0 <= i < 16384 and a small divisor (exact while i * (m * D - 2^20) < 2^20, which the assert bounds): one 24-bit
+// multiply and a shift instead of the quarter-rate 32-bit multiply-high of a general division.
+template <unsigned D>
+__device__ __forceinline__ int div_small(int i) {
+    constexpr unsigned m = ((1u << 20) + D - 1) / D;
+    static_assert(m * D - (1u << 20) < 64, "multiplier error too large for i < 16384");
+    return (int)(__umul24((unsigned)i, m) >> 20);
+}
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ short2v as_short2v(unsigned w) { return __builtin_bit_cast(short2v, w); }
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
 #pragma unroll
         for (int k = 0; k < kSteps; k++) {
             const int i = min(tid + 256 * k, kSegs - 1);
-            const int r = i / (kFPitch / 16), c = i - r * (kFPitch / 16);
+            const int r = div_small<kFPitch / 16>(i), c = i - r * (kFPitch / 16);
             const int ay = min(oy + r, g.atlas_h - 1);
             tmp[k] = load_u128_any(fb + (size_t)ay * aw + abase + 16 * c);
         }
@@ -347,9 +356,9 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     const int n1 = empty ? 0 : (ye - ys) * kFGroups;
     for (int base = 0; base < n1; base += 256) {
         const int item = min(base + tid, n1 - 1);
-        const int r = item / kFGroups, gq = item - r * kFGroups;
+        const int r = div_small<kFGroups>(item), gq = item - __mul24(r, kFGroups);
         const int y = ys + r;
-        const unsigned* tr = t32 + (y - tl.y0 + 4) * (kFPitch / 4) + gq;
+        const unsigned* tr = t32 + __mul24(y - tl.y0 + 4, kFPitch / 4) + gq;
         const unsigned C = tr[0], Lw = tr[-1], Rw = tr[1];
         const unsigned P0 = tr[3 * (kFPitch / 4)], P8 = tr[-3 * (kFPitch / 4)];
         const unsigned P4 = __builtin_amdgcn_alignbyte(Rw, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         if (lane == 0) qb = atomicAdd(&q_count, total);
         qb = __builtin_amdgcn_readfirstlane(qb);
         const unsigned long long below = (1ull << lane) - 1ull;
-        const int code = r * kQCols + 4 * gq;  // (row of the ring-grown tile, staged column)
+        const int code = __mul24(r, kQCols) + 4 * gq;  // (row of the ring-grown tile, staged column)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if ((pass[j] >> lane) & 1ull) queue[qb + __popcll(pass[j] & below)] = (unsigned short)(code + j);
@@ -392,16 +401,16 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     const int nq = q_count;
     for (int q = tid; q < nq; q += 256) {
         const int code = queue[q];
-        const int rr = code / kQCols;
-        const int x = tl.x0 - 4 - off + (code - rr * kQCols);  // level x of the queued pixel
+        const int rr = div_small<kQCols>(code);
+        const int x = tl.x0 - 4 - off + (code - __mul24(rr, kQCols));  // level x of the queued pixel
         if (x < xs || x >= xe) {
             queue[q] = 0xffffu;
             continue;
         }
         const int r = ys + rr - tl.y0 + 1, c = x - tl.x0 + 1;   // position in the ring-grown score tile
-        const int pos = r * kSW + c;
+        const int pos = __mul24(r, kSW) + c;
         queue[q] = (unsigned short)pos;
-        const uint8_t* ctr = t + (r + 3) * kFPitch + c + 3 + off;
+        const uint8_t* ctr = t + __mul24(r + 3, kFPitch) + c + 3 + off;
         const int v = ctr[0];
         int d[16], m2[16], m4[16], x2[16], x4[16];
 #pragma unroll
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         const int pos = queue[q];
         if (pos == 0xffff) continue;
         const int c = st[pos];
-        const int r = pos / kSW - 1, cc = pos - (r + 1) * kSW - 1;
+        const int r = div_small<kSW>(pos) - 1, cc = pos - __mul24(r + 1, kSW) - 1;
         bool kp = false;
         if (c != 0 && r >= 0 && r < kTileH && cc >= 0 && cc < kTileW) {
             const int y = tl.y0 + r, x = tl.x0 + cc;
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     for (int q = tid; q < nq; q += 256) {
         const int pos = queue[q];
         if (pos == 0xffff) continue;
-        const int r = pos / kSW - 1, cc = pos - (r + 1) * kSW - 1;
+        const int r = div_small<kSW>(pos) - 1, cc = pos - __mul24(r + 1, kSW) - 1;
         const unsigned long long row = (unsigned long long)s_mask[2 * r] | ((unsigned long long)s_mask[2 * r + 1] << 32);
         const int rank = __popcll(row & ((1ull << cc) - 1ull));
         const unsigned c = st[pos];
@@ -1036,14 +1045,17 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
     const int rows = min(kStripRows, L.h - y0);
     const int aw = g.atlas_w;
     const size_t fo = (size_t)blockIdx.y * atlas_bytes;
-    const uint8_t* src = atlas + fo + (size_t)(L.y + y0 - 3) * aw + ax;
-    uint8_t* dst = blurred + fo + (size_t)(L.y + y0) * aw + ax;
+    // uniform frame base + 32-bit lane offset (an atlas is far smaller than 4 GB): no 64-bit multiplies per row
+    const uint8_t* src = atlas + fo;
+    uint8_t* dst = blurred + fo;
+    const unsigned so = (unsigned)(L.y + y0 - 3) * (unsigned)aw + (unsigned)ax - 4u;
+    const unsigned d_o = (unsigned)(L.y + y0) * (unsigned)aw + (unsigned)ax;
     // Straight-line code: every row load is unconditional (row index clamped into the strip's own rows, whose
     // results are then simply not stored), so the loads of later rows are in flight while earlier rows are filtered.
     struct Row3 { unsigned lft, c, rgt; };
     auto load_row = [&](int r) {
         Row3 v;
-        __builtin_memcpy(&v, src + (size_t)min(r, rows + 5) * aw - 4, 12);
+        __builtin_memcpy(&v, src + (so + __umul24((unsigned)min(r, rows + 5), (unsigned)aw)), 12);
         return v;
     };
     constexpr int kBlurAhead = 8;
@@ -1069,12 +1081,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // rows r-6 .. r hold taps 0 .. 6 (symmetric): k3*h3 + k2*(h2+h4) + k1*(h1+h5) + k0*(h0+h6)
-                const unsigned v = bt.k[3] * h[(r - 3) % 7][j] + bt.k[2] * (h[(r - 4) % 7][j] + h[(r - 2) % 7][j]) +
-                                   bt.k[1] * (h[(r - 5) % 7][j] + h[(r - 1) % 7][j]) +
-                                   bt.k[0] * (h[(r - 6) % 7][j] + h[r % 7][j]);
+                // 24-bit multiplies (full rate; a 32-bit integer multiply issues at a quarter of it): taps <= 256, sums < 2^17
+                const unsigned v = __umul24(bt.k[3], h[(r - 3) % 7][j]) +
+                                   __umul24(bt.k[2], h[(r - 4) % 7][j] + h[(r - 2) % 7][j]) +
+                                   __umul24(bt.k[1], h[(r - 5) % 7][j] + h[(r - 1) % 7][j]) +
+                                   __umul24(bt.k[0], h[(r - 6) % 7][j] + h[r % 7][j]);
                 out |= min((v + (1u << 15)) >> 16, 255u) << (8 * j);
             }
-            if (r - 6 < rows) *(unsigned*)(dst + (size_t)(r - 6) * aw) = out;
+            if (r - 6 < rows) *(unsigned*)(dst + (d_o + __umul24((unsigned)(r - 6), (unsigned)aw))) = out;
         }
     }
 }
@@ -1153,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
         for (int k = 0; k < kSteps; k++) {  // all row loads in flight, then the LDS stores
             const int i = min(lane + 32 * k, kDwords - 1);
             const int r = i / (kBriefPitch / 4), c = i - r * (kBriefPitch / 4);
-            tmp[k] = load_u32_any(corner + (ptrdiff_t)r * aw + 4 * c);
+            tmp[k] = load_u32_any(corner + (__umul24((unsigned)r, (unsigned)aw) + 4u * (unsigned)c));
         }
 #pragma unroll
         for (int k = 0; k < kSteps; k++)
@@ -1175,8 +1189,8 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
         const int dx1 = __float2int_rn(x1), dy1 = __float2int_rn(y1);
         int t0, t1;
         if (staged) {
-            t0 = sp8[dy0 * kBriefPitch + dx0];
-            t1 = sp8[dy1 * kBriefPitch + dx1];
+            t0 = sp8[__mul24(dy0, kBriefPitch) + dx0];
+            t1 = sp8[__mul24(dy1, kBriefPitch) + dx1];
         } else {
             const int sx0 = cx + dx0, sy0 = cy + dy0, sx1 = cx + dx1, sy1 = cy + dy1;
             const bool in0 = (unsigned)sx0 < (unsigned)lw && (unsigned)sy0 < (unsigned)lh;
