@@ -412,26 +412,28 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         queue[q] = (unsigned short)pos;
         const uint8_t* ctr = t + __mul24(r + 3, kFPitch) + c + 3 + off;
         const int v = ctr[0];
-        int d[16], m2[16], m4[16], x2[16], x4[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - (int)ctr[dy[k] * kFPitch + dx[k]];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            m2[k] = min(d[k], d[(k + 1) & 15]);
-            x2[k] = max(d[k], d[(k + 1) & 15]);
-        }
+        // Pairs of 16-bit halves (d, -d), d = v - ring pixel: the minimum over an arc of nine of the low halves is the
+        // bright-side margin, of the high halves the dark-side one (-max d = min -d), so one packed minimum tree
+        // serves both.  m2/m4/m8: minima over 2, 4, 8 consecutive ring positions starting at k; m9 adds the ninth.
+        const short2v vn = as_short2v(((unsigned)v & 0xffffu) | ((unsigned)(-v) << 16));
+        const short2v sg = {(short)-1, (short)1};
+        short2v P[16], m2[16], m4[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            m4[k] = min(m2[k], m2[(k + 2) & 15]);
-            x4[k] = max(x2[k], x2[(k + 2) & 15]);
+            const unsigned r8 = ctr[dy[k] * kFPitch + dx[k]];
+            P[k] = as_short2v(__umul24(r8, 0x10001u)) * sg + vn;
         }
-        int best = threshold;
+#pragma unroll
+        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(P[k], P[(k + 1) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+        short2v acc = {(short)-32768, (short)-32768};
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int mn = min(min(m4[k], m4[(k + 4) & 15]), d[(k + 8) & 15]);
-            const int mx = max(max(x4[k], x4[(k + 4) & 15]), d[(k + 8) & 15]);
-            best = max(best, max(mn, -mx));
+            const short2v m8 = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+            acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(m8, P[(k + 8) & 15]));
         }
+        const int best = max(threshold, max((int)acc.x, (int)acc.y));
         if (best > threshold) st[pos] = (uint8_t)(best - 1);  // an arc of nine clears the band <=> a corner
     }
     __syncthreads();
