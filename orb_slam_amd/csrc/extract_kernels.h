@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         const int thr = base + tid < n1 ? threshold : 1024;
         // two pixels per instruction: even pixels of the dword in one pair of 16-bit halves, odd pixels in another
         unsigned long long pass[4];
+        bool mine[4];
         int total = 0;
 #pragma unroll
         for (int hsel = 0; hsel < 2; hsel++) {
@@ -380,19 +381,24 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             const short2v up = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)) - v;
             const short2v dn = v - __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
             const short2v m = __builtin_elementwise_max(up, dn);
-            pass[hsel] = __ballot(m.x > (short)thr);
-            pass[hsel + 2] = __ballot(m.y > (short)thr);
+            mine[hsel] = m.x > (short)thr;
+            mine[hsel + 2] = m.y > (short)thr;
+            pass[hsel] = __ballot(mine[hsel]);
+            pass[hsel + 2] = __ballot(mine[hsel + 2]);
             total += __popcll(pass[hsel]) + __popcll(pass[hsel + 2]);
         }
         if (total == 0) continue;
         int qb = 0;
         if (lane == 0) qb = atomicAdd(&q_count, total);
         qb = __builtin_amdgcn_readfirstlane(qb);
-        const unsigned long long below = (1ull << lane) - 1ull;
         const int code = __mul24(r, kQCols) + 4 * gq;  // (row of the ring-grown tile, staged column)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if ((pass[j] >> lane) & 1ull) queue[qb + __popcll(pass[j] & below)] = (unsigned short)(code + j);
+            // rank among the passing lanes below this one, counted by the mask-bit-count pair on top of the base
+            if (mine[j])
+                queue[__builtin_amdgcn_mbcnt_hi((unsigned)(pass[j] >> 32),
+                                                __builtin_amdgcn_mbcnt_lo((unsigned)pass[j], (unsigned)qb))] =
+                    (unsigned short)(code + j);
             qb += __popcll(pass[j]);
         }
     }
