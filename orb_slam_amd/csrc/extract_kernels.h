@@ -454,8 +454,10 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             const int y = tl.y0 + r, x = tl.x0 + cc;
             if (level_ok && x >= lo && x < L.w - lo && y >= lo && y < L.h - lo) {
                 const uint8_t* s = st + pos;
-                kp = c > s[1] && c > s[-1] && c > s[-kSW - 1] && c > s[-kSW] && c > s[-kSW + 1] && c > s[kSW - 1] &&
-                     c > s[kSW] && c > s[kSW + 1];
+                // all eight neighbours read at once (no short circuit: one LDS round trip instead of up to eight)
+                const int n0 = s[1], n1 = s[-1], n2 = s[-kSW - 1], n3 = s[-kSW], n4 = s[-kSW + 1], n5 = s[kSW - 1],
+                          n6 = s[kSW], n7 = s[kSW + 1];
+                kp = c > max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
             }
         }
         if (kp) atomicOr(&s_mask[2 * r + (cc >> 5)], 1u << (cc & 31));
