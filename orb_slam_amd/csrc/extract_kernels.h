@@ -668,14 +668,16 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 struct UMax { int v[16]; };
 
-// Sum over the wavefront, returned as a wave-uniform value (row reduction with DPP, rows combined by readlane).
-__device__ __forceinline__ int wave_sum_uniform(int v) {
+// Sum over the wavefront, valid in lane 63 only (row reduction, then the two cross-row broadcasts): no scalar
+// round trip, for results that one lane consumes.
+__device__ __forceinline__ int wave_sum_lane63(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-           __builtin_amdgcn_readlane(v, 48);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
+    return v;
 }
 
 // K5/K6: Harris response (cv::ORB HarrisResponses, 7x7 block, k = 0.04) and intensity-centroid angle
@@ -769,10 +771,10 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
                 ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
                 wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
             }
-            const int sha = wave_sum_uniform(ha), shb = wave_sum_uniform(hb), shc = wave_sum_uniform(hc);
-            const int m10 = wave_sum_uniform(right ? (int)wsum : -(int)wsum);
-            const int m01 = wave_sum_uniform(v * (int)ssum);
-            if (lane == 0) {
+            const int sha = wave_sum_lane63(ha), shb = wave_sum_lane63(hb), shc = wave_sum_lane63(hc);
+            const int m10 = wave_sum_lane63(right ? (int)wsum : -(int)wsum);
+            const int m01 = wave_sum_lane63(v * (int)ssum);
+            if (lane == 63) {
                 const float fa = (float)sha, fb2 = (float)shb, fc = (float)shc;
                 const float resp = (fa * fb2 - fc * fc - 0.04f * (fa + fb2) * (fa + fb2)) * scale_sq_sq;
                 Cand* cp = cbase + idx;
