@@ -320,8 +320,19 @@ void launch_resize(orbx_extractor* h, int l, int frames, hipStream_t s) {
     const orbx_extractor::ResizePlan& rp = h->rplan[l];
     const int rows = g.L[l].h + 2 * g.border;
     if (rp.narrow) {
-        dim3 grid(div_up(rp.n_dwords, 64), div_up(rows, 4 * kResizeRows), frames);
-        hipLaunchKernelGGL(k_resize_strip, grid, dim3(256), 0, s, h->d_atlas.p, h->atlas_bytes, g.atlas_w, g.L[l],
+        // lanes across a strip: 64, or 32 / 16 (with 2 / 4 row blocks per wavefront) when that leaves clearly fewer
+        // lanes idle past the level's right edge
+        auto used = [&](int gw) { return (double)rp.n_dwords / (div_up(rp.n_dwords, gw) * gw); };
+        int gw = 64;
+        // (the per-lane-group form costs about a tenth more per lane: measured, it pays from a quarter fewer idle lanes)
+        if (used(32) > used(64) * 1.25) {
+            gw = 32;
+            if (used(16) > used(32) * 1.15) gw = 16;
+        }
+        const int row_blocks = div_up(rows, kResizeRows);
+        dim3 grid(div_up(rp.n_dwords, gw), div_up(row_blocks, 4 * (64 / gw)), frames);
+        auto kern = gw == 64 ? k_resize_strip : gw == 32 ? k_resize_strip_sub<32> : k_resize_strip_sub<16>;
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, h->d_atlas.p, h->atlas_bytes, g.atlas_w, g.L[l],
                            g.border, h->d_coefx.p + rp.cx_off, h->d_coefy.p + rp.cy_off, rp.ax_begin, rp.n_dwords);
     } else {
         dim3 grid(div_up(rp.n_dwords, 64), div_up(rows, 4), frames);

@@ -259,6 +259,104 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
     }
 }
 
+// K2 (strip form, narrow levels): the same work with G = 32 or 16 lanes across and 64 / G row blocks per wavefront, for
+// levels whose width in dwords would leave most of a second 64-lane strip idle.  Everything that is per wavefront in
+// k_resize_strip (row block, source row range, row coefficients) is per lane group here.
+template <int G>
+__global__ __launch_bounds__(256) void k_resize_strip_sub(uint8_t* __restrict__ atlas, size_t atlas_bytes, int aw,
+                                                          LevelInfo dst, int border, const CoefX* __restrict__ cxs,
+                                                          const CoefY* __restrict__ cys, int ax_begin, int n_dwords) {
+    __shared__ uint2 s_h[4][kResizeSrcRows][64];
+    constexpr int kBlocks = 64 / G;  // row blocks per wavefront
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % G, sub = lane / G;
+    const int dc = blockIdx.x * G + gl;
+    const int wv = threadIdx.x >> 6;
+    const int rows = dst.h + 2 * border;
+    const int ty0 = ((blockIdx.y * 4 + wv) * kBlocks + sub) * kResizeRows;
+    const bool rows_ok = ty0 < rows;
+    if (__ballot(rows_ok) == 0ull) return;
+    const int ty1 = min(ty0 + kResizeRows, rows);
+    CoefY cyv[kResizeRows];
+    int r_lo = 0x7fffffff, r_hi = -1;
+#pragma unroll
+    for (int t = 0; t < kResizeRows; t++) {
+        cyv[t] = cys[min(ty0 + t, rows - 1)];  // rows past the end repeat the last one: the range is unchanged
+        r_lo = min(r_lo, min(cyv[t].row0, cyv[t].row1));
+        r_hi = max(r_hi, max(cyv[t].row0, cyv[t].row1));
+    }
+    const int n_src = r_hi - r_lo + 1;
+    const bool live = rows_ok && dc < n_dwords;
+    const uint4 raw = *(const uint4*)(cxs + (live ? dc : 0) * 4);
+    const unsigned cw[4] = {raw.x, raw.y, raw.z, raw.w};
+    int sx[4];
+    bool ok[4];
+    unsigned wgt[4], stepmask = 0;
+    int lo = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        sx[j] = (int)(short)(cw[j] & 0xffffu);
+        const unsigned f = cw[j] >> 16;
+        const unsigned w1 = f & 0x1ffu;
+        wgt[j] = (256u - w1) | (w1 << 16);
+        if ((f >> 14) & 1u) stepmask |= 0xffu << (8 * j);
+        ok[j] = live && (f >> 15) != 0;
+        if (ok[j]) lo = min(lo, sx[j]);
+    }
+    const bool any = lo != 0x7fffffff;
+    const int base = any ? lo & ~3 : 0;
+    unsigned sel = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) sel |= (unsigned)(ok[j] ? sx[j] - base : 0) << (8 * j);
+    uint8_t* fb = atlas + (size_t)blockIdx.z * atlas_bytes;
+    struct Row3 { unsigned d0, d1, d2; };
+    Row3 src[kResizeSrcRows];
+#pragma unroll
+    for (int k = 0; k < kResizeSrcRows; k++)
+        __builtin_memcpy(&src[k], fb + ((unsigned)__umul24((unsigned)min(r_lo + k, r_hi), (unsigned)aw) + (unsigned)base), 12);
+#pragma unroll
+    for (int k = 0; k < kResizeSrcRows; k++) {
+        if (k < n_src) {
+            const unsigned d0 = src[k].d0, d1 = src[k].d1, d2 = src[k].d2;
+            const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, 1), e1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+            const unsigned A4 = __builtin_amdgcn_perm(d1, d0, sel);
+            unsigned B4 = __builtin_amdgcn_perm(e1, e0, sel);
+            B4 = (B4 & stepmask) | (A4 & ~stepmask);
+            unsigned hh[4];
+            const unsigned ab[4] = {__builtin_amdgcn_perm(B4, A4, 0x0c040c00u), __builtin_amdgcn_perm(B4, A4, 0x0c050c01u),
+                                    __builtin_amdgcn_perm(B4, A4, 0x0c060c02u), __builtin_amdgcn_perm(B4, A4, 0x0c070c03u)};
+#pragma unroll
+            for (int j = 0; j < 4; j++) hh[j] = __umul24(ab[j] & 0xffffu, wgt[j] & 0xffffu) + __umul24(ab[j] >> 16, wgt[j] >> 16);
+            s_h[wv][k][lane] = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!any) return;
+    const bool whole = ok[0] && ok[1] && ok[2] && ok[3];
+#pragma unroll
+    for (int t = 0; t < kResizeRows; t++) {
+        const int ty = ty0 + t;
+        if (ty >= ty1) break;
+        const CoefY cy = cyv[t];
+        const uint2 a = s_h[wv][cy.row0 - r_lo][lane], b = s_h[wv][cy.row1 - r_lo][lane];
+        const unsigned wy1 = (unsigned)cy.w1, wy0 = 256u - wy1;
+        const unsigned ah[4] = {a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16};
+        const unsigned bh[4] = {b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16};
+        unsigned out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) out |= ((__umul24(wy0, ah[j]) + __umul24(wy1, bh[j]) + (1u << 15)) >> 16) << (8 * j);
+        uint8_t* d = fb + (size_t)(dst.y - border + ty) * aw + ax_begin + dc * 4;
+        if (whole) *(unsigned*)d = out;
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ok[j]) d[j] = (uint8_t)(out >> (8 * j));
+        }
+    }
+}
+
 // K3+K4a fused: FAST-9/16 score and 3x3 strict non-max suppression of one 64 x kTileH tile, never leaving LDS.
 //   phase 1  every pixel of the tile (plus a one-pixel ring for the suppression) takes the four-point compass test,
 //            four pixels per lane from whole staged dwords, evaluated on 64-bit lane masks with scalar logic; the
