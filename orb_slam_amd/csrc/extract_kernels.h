@@ -159,6 +159,25 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ atl
     }
 }
 
+// a.lo * b.lo + a.hi * b.hi + c on the 16-bit halves (v_dot2_u32_u16).
+__device__ __forceinline__ unsigned udot2_u16(unsigned a, unsigned b, unsigned c) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+}
+
+// Vertical blend of two parked rows of horizontal sums (four 16-bit sums in a uint2 each) with the Q8 weight w1 of
+// the lower row: ((256 - w1) * a + w1 * b + 2^15) >> 16 per pixel, four pixels packed into a dword.  The sums of a
+// pixel are paired into one register (v_perm), one dot product per pixel does the blend and the rounding, and two
+// more v_perm collect byte 2 of the four results.
+__device__ __forceinline__ unsigned blend_rows_q8(uint2 a, uint2 b, unsigned w1) {
+    const unsigned wy = (256u - w1) | (w1 << 16);
+    const unsigned r0 = udot2_u16(__builtin_amdgcn_perm(b.x, a.x, 0x05040100u), wy, 1u << 15);
+    const unsigned r1 = udot2_u16(__builtin_amdgcn_perm(b.x, a.x, 0x07060302u), wy, 1u << 15);
+    const unsigned r2 = udot2_u16(__builtin_amdgcn_perm(b.y, a.y, 0x05040100u), wy, 1u << 15);
+    const unsigned r3 = udot2_u16(__builtin_amdgcn_perm(b.y, a.y, 0x07060302u), wy, 1u << 15);
+    return __builtin_amdgcn_perm(r1, r0, 0x0c0c0602u) | __builtin_amdgcn_perm(r3, r2, 0x06020c0cu);
+}
+
 // K2 (strip form, for scale factors whose four-pixel source span fits two dwords and whose kResizeRows output rows
 // draw on at most kResizeSrcRows source rows): a wavefront produces kResizeRows output rows of a 256-pixel-wide
 // column strip.  Everything that depends only on x - byte selectors, weights, clamp mask - is set up once per lane.
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
             const unsigned ab[4] = {__builtin_amdgcn_perm(B4, A4, 0x0c040c00u), __builtin_amdgcn_perm(B4, A4, 0x0c050c01u),
                                     __builtin_amdgcn_perm(B4, A4, 0x0c060c02u), __builtin_amdgcn_perm(B4, A4, 0x0c070c03u)};
 #pragma unroll
-            for (int j = 0; j < 4; j++) hh[j] = __umul24(ab[j] & 0xffffu, wgt[j] & 0xffffu) + __umul24(ab[j] >> 16, wgt[j] >> 16);
+            for (int j = 0; j < 4; j++) hh[j] = udot2_u16(ab[j], wgt[j], 0u);
             s_h[wv][k][lane] = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));  // each sum <= 255 * 256
         }
     }
@@ -243,12 +262,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(uint8_t* __restrict__ atla
     for (int ty = ty0; ty < ty1; ty++) {
         const CoefY cy = cys[ty];
         const uint2 a = s_h[wv][cy.row0 - r_lo][lane], b = s_h[wv][cy.row1 - r_lo][lane];
-        const unsigned wy1 = (unsigned)cy.w1, wy0 = 256u - wy1;
-        const unsigned ah[4] = {a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16};
-        const unsigned bh[4] = {b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16};
-        unsigned out = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) out |= ((__umul24(wy0, ah[j]) + __umul24(wy1, bh[j]) + (1u << 15)) >> 16) << (8 * j);
+        const unsigned out = blend_rows_q8(a, b, (unsigned)cy.w1);
         uint8_t* d = fb + (size_t)(dst.y - border + ty) * aw + ax_begin + dc * 4;
         if (whole) *(unsigned*)d = out;
         else {
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(256) void k_resize_strip_sub(uint8_t* __restrict__ 
             const unsigned ab[4] = {__builtin_amdgcn_perm(B4, A4, 0x0c040c00u), __builtin_amdgcn_perm(B4, A4, 0x0c050c01u),
                                     __builtin_amdgcn_perm(B4, A4, 0x0c060c02u), __builtin_amdgcn_perm(B4, A4, 0x0c070c03u)};
 #pragma unroll
-            for (int j = 0; j < 4; j++) hh[j] = __umul24(ab[j] & 0xffffu, wgt[j] & 0xffffu) + __umul24(ab[j] >> 16, wgt[j] >> 16);
+            for (int j = 0; j < 4; j++) hh[j] = udot2_u16(ab[j], wgt[j], 0u);
             s_h[wv][k][lane] = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
         }
     }
@@ -341,12 +355,7 @@ __global__ __launch_bounds__(256) void k_resize_strip_sub(uint8_t* __restrict__ 
         if (ty >= ty1) break;
         const CoefY cy = cyv[t];
         const uint2 a = s_h[wv][cy.row0 - r_lo][lane], b = s_h[wv][cy.row1 - r_lo][lane];
-        const unsigned wy1 = (unsigned)cy.w1, wy0 = 256u - wy1;
-        const unsigned ah[4] = {a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16};
-        const unsigned bh[4] = {b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16};
-        unsigned out = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) out |= ((__umul24(wy0, ah[j]) + __umul24(wy1, bh[j]) + (1u << 15)) >> 16) << (8 * j);
+        const unsigned out = blend_rows_q8(a, b, (unsigned)cy.w1);
         uint8_t* d = fb + (size_t)(dst.y - border + ty) * aw + ax_begin + dc * 4;
         if (whole) *(unsigned*)d = out;
         else {
