@@ -881,7 +881,8 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
                     const int d = __popc(ra.x ^ w1[u].x) + __popc(ra.y ^ w1[u].y) + __popc(ra.z ^ w1[u].z) +
                                   __popc(ra.w ^ w1[u].w) + __popc(rb.x ^ w2[u].x) + __popc(rb.y ^ w2[u].y) +
                                   __popc(rb.z ^ w2[u].z) + __popc(rb.w ^ w2[u].w);
-                    s_ent[grp][pos] = make_int2((int)(r.idx_oct & 0xffffffu), d);
+                    // the sort key goes in with the entry: distance << 8 | (255 - scan position), distinct per entry
+                    s_ent[grp][pos] = make_int2((int)(r.idx_oct & 0xffffffu), (d << 8) | (255 - pos));
                 }
                 list_n += __popc(gm);
             }
@@ -895,13 +896,9 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
     int2* list = A.win_list + (size_t)ref_idx * kSortK;
     for (int i = gl; i < list_n; i += 16) {
         const int2 e = s_ent[grp][i];
-        const unsigned key = ((unsigned)e.y << 8) | (unsigned)(255 - i);
         int rank = 0;
-        for (int j = 0; j < list_n; j++) {
-            const unsigned kj = ((unsigned)s_ent[grp][j].y << 8) | (unsigned)(255 - j);
-            rank += kj < key;
-        }
-        list[rank] = e;
+        for (int j = 0; j < list_n; j++) rank += s_ent[grp][j].y < e.y;
+        list[rank] = make_int2(e.x, e.y >> 8);
     }
 }
 
