@@ -848,6 +848,17 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
         s_incl[grp][gl] = incl;
         s_first[grp][gl] = start - (incl - len);  // record of item t of this run = first + t
         wave_lds_fence();
+        // the first four runs of the chunk (a window is rarely wider) reach every lane of the group through DPP row
+        // broadcasts; only a record beyond them looks its run up in LDS
+        const int first = start - (incl - len);
+        const int i0 = __builtin_amdgcn_update_dpp(0, incl, 0x150, 0xF, 0xF, false);
+        const int i1 = __builtin_amdgcn_update_dpp(0, incl, 0x151, 0xF, 0xF, false);
+        const int i2 = __builtin_amdgcn_update_dpp(0, incl, 0x152, 0xF, 0xF, false);
+        const int i3 = __builtin_amdgcn_update_dpp(0, incl, 0x153, 0xF, 0xF, false);
+        const int f0 = __builtin_amdgcn_update_dpp(0, first, 0x150, 0xF, 0xF, false);
+        const int f1 = __builtin_amdgcn_update_dpp(0, first, 0x151, 0xF, 0xF, false);
+        const int f2 = __builtin_amdgcn_update_dpp(0, first, 0x152, 0xF, 0xF, false);
+        const int f3 = __builtin_amdgcn_update_dpp(0, first, 0x153, 0xF, 0xF, false);
         // two records per lane and step: both fetches are in flight together
         for (int tb = 0; tb < total && list_n <= kSortK; tb += 32) {
             uint4 w0[2], w1[2], w2[2];
@@ -858,9 +869,13 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
                 in[u] = t < total;
                 w0[u] = w1[u] = w2[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (in[u]) {
-                    int run = 0;
-                    while (t >= s_incl[grp][run]) run++;
-                    const uint4* rp = (const uint4*)(recs + s_first[grp][run] + t);
+                    int fr = t < i0 ? f0 : t < i1 ? f1 : t < i2 ? f2 : f3;
+                    if (t >= i3) {
+                        int run = 4;
+                        while (t >= s_incl[grp][run]) run++;
+                        fr = s_first[grp][run];
+                    }
+                    const uint4* rp = (const uint4*)(recs + fr + t);
                     w0[u] = rp[0];
                     w1[u] = rp[1];
                     w2[u] = rp[2];
