@@ -889,13 +889,20 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
                 r.idx_oct = w0[u].z;
                 r.cx = (uint16_t)(w0[u].w & 0xffffu);
                 r.cy = (uint16_t)(w0[u].w >> 16);
-                const bool ok = in[u] && in_window_rec(r, W);
+                // A candidate farther than the acceptance bound (orb_matcher.cpp:228, 100) can never be assigned: the
+                // resolve step stops a point at its first free entry beyond the bound, which is the same as finding
+                // no free entry among those within it.  Only the latter are listed (a few per window).
+                bool ok = in[u] && in_window_rec(r, W);
+                int d = 0;
+                if (ok) {
+                    d = __popc(ra.x ^ w1[u].x) + __popc(ra.y ^ w1[u].y) + __popc(ra.z ^ w1[u].z) +
+                        __popc(ra.w ^ w1[u].w) + __popc(rb.x ^ w2[u].x) + __popc(rb.y ^ w2[u].y) +
+                        __popc(rb.z ^ w2[u].z) + __popc(rb.w ^ w2[u].w);
+                    ok = d <= 100;
+                }
                 const unsigned gm = (unsigned)(__ballot(ok) >> (16 * sub)) & 0xffffu;
                 const int pos = list_n + __popc(gm & ((1u << gl) - 1u));
                 if (ok && pos < kSortK) {
-                    const int d = __popc(ra.x ^ w1[u].x) + __popc(ra.y ^ w1[u].y) + __popc(ra.z ^ w1[u].z) +
-                                  __popc(ra.w ^ w1[u].w) + __popc(rb.x ^ w2[u].x) + __popc(rb.y ^ w2[u].y) +
-                                  __popc(rb.z ^ w2[u].z) + __popc(rb.w ^ w2[u].w);
                     // the sort key goes in with the entry: distance << 8 | (255 - scan position), distinct per entry
                     s_ent[grp][pos] = make_int2((int)(r.idx_oct & 0xffffffu), (d << 8) | (255 - pos));
                 }
