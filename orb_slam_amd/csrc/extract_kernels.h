@@ -796,6 +796,8 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
                                                       Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
                                                       const int* __restrict__ thresholds, UMax umax,
                                                       float scale_sq_sq, int chunks, int frames) {
+    // per wavefront: the five sums and the index of up to 64 reduced candidates, finished 64 at a time (below)
+    __shared__ int s_res[4][64][6];
     const int lane = threadIdx.x & 63;
     int b, chunk;
     if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
@@ -851,6 +853,27 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
         }
         return p;
     };
+    // The response and the angle of a candidate are scalar work (a division, a polynomial): done right after the
+    // reduction they would occupy the whole wavefront for one lane's result.  The sums are parked instead and every
+    // lane finishes one candidate when 64 have gathered (and once more at the end).
+    int (*res)[6] = s_res[threadIdx.x >> 6];
+    int n_res = 0;
+    auto finish = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < n_res) {
+            const float fa = (float)res[lane][0], fb2 = (float)res[lane][1], fc = (float)res[lane][2];
+            const float resp = (fa * fb2 - fc * fc - 0.04f * (fa + fb2) * (fa + fb2)) * scale_sq_sq;
+            Cand* cp = cbase + res[lane][5];
+            cp->harris = resp;
+            cp->angle = fast_atan2_deg((float)res[lane][4], (float)res[lane][3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        n_res = 0;
+    };
     Cand c_cur = cbase[min(idx0, max(total - 1, 0))];
     Cand c_nxt = cbase[min(idx0 + stride, max(total - 1, 0))];
     Px px_cur = fetch_px(c_cur, idx0 < total);
@@ -882,17 +905,21 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
             const int m10 = wave_sum_lane63(right ? (int)wsum : -(int)wsum);
             const int m01 = wave_sum_lane63(v * (int)ssum);
             if (lane == 63) {
-                const float fa = (float)sha, fb2 = (float)shb, fc = (float)shc;
-                const float resp = (fa * fb2 - fc * fc - 0.04f * (fa + fb2) * (fa + fb2)) * scale_sq_sq;
-                Cand* cp = cbase + idx;
-                cp->harris = resp;
-                cp->angle = fast_atan2_deg((float)m01, (float)m10);
+                res[n_res][0] = sha;
+                res[n_res][1] = shb;
+                res[n_res][2] = shc;
+                res[n_res][3] = m10;
+                res[n_res][4] = m01;
+                res[n_res][5] = idx;
             }
+            n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
+            if (n_res == 64) finish();
         }
         c_cur = c_nxt;
         c_nxt = c_nn;
         px_cur = px_nxt;
     }
+    if (n_res > 0) finish();
 }
 
 // Frame model of MonoFrame::extractFeatures for the device-resident batch path.
