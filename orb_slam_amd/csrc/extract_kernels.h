@@ -401,9 +401,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     __shared__ __align__(16) unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
     __shared__ unsigned short queue[kQCols * kSH];
-    __shared__ unsigned s_mask[2 * kTileH];
-    __shared__ unsigned s_sc8[2 * kTileH];
     __shared__ int q_count;
+    // the row masks and their packed scores are first needed in phase 3, when the staged pixels are dead: they share
+    // the staging buffer, which brings a tile's LDS under 20 KB - eight tiles per CU instead of seven
+    unsigned* s_mask = t32;
+    unsigned* s_sc8 = t32 + 2 * kTileH;
     uint8_t* t = (uint8_t*)t32;
     uint8_t* st = (uint8_t*)s32;
     // workgroups go round-robin over the 8 XCDs (each with its own L2): give every XCD one contiguous run of tiles,
@@ -451,10 +453,6 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             if (tid + 256 * k < kSegs) ((uint4*)t32)[tid + 256 * k] = tmp[k];
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
-    if (tid < 2 * kTileH) {
-        s_mask[tid] = 0u;
-        s_sc8[tid] = 0u;
-    }
     if (tid == 0) q_count = 0;
     __syncthreads();
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -548,6 +546,11 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         }
         const int best = max(threshold, max((int)acc.x, (int)acc.y));
         if (best > threshold) st[pos] = (uint8_t)(best - 1);  // an arc of nine clears the band <=> a corner
+    }
+    __syncthreads();
+    if (tid < 2 * kTileH) {
+        s_mask[tid] = 0u;
+        s_sc8[tid] = 0u;
     }
     __syncthreads();
     // phase 3: suppression and border rule for the queued corners of the tile proper; bits gathered per tile row
