@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64) void k_resolve_lists(ProjArgs A) {
 // ---- batched frame-to-frame matcher: records -> sorted window lists -> speculative resolve -------------------------
 
 // One feature of a frame in the order of the CSR bucket grid, with everything the window test reads.
-constexpr int kSortK = 128;  // entries per reference point in the sorted window lists
+constexpr int kSortK = 64;   // entries per reference point in the sorted window lists (candidates within the bound)
 
 struct ItemRec {
     float x, y;
@@ -811,7 +811,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // the first entry that is still free.
 // win_n[ref] = -1: point skipped; > kSortK: list too long, the resolve step scans that window itself.
 __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec* __restrict__ recs_all) {
-    __shared__ int2 s_ent[16][kSortK];
+    __shared__ int2 s_ent[16][kSortK + 1];  // + 1: the groups' lists start in different banks
     __shared__ int s_incl[16][16];
     __shared__ int s_first[16][16];
     __shared__ float s_sf[64];
@@ -1831,7 +1831,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     A.status = h->d_ints.p;
     A.n_matches = d_n_matches;
     ORBX_TRY(h->d_win_n.ensure((size_t)kp_capacity * n_pairs));
-    ORBX_TRY(h->d_win_list.ensure((size_t)kp_capacity * n_pairs * kSortK));
+    ORBX_TRY(h->d_win_list.ensure((size_t)kp_capacity * n_pairs * (kp_capacity > 6144 ? kWinK : kSortK)));
     ORBX_TRY(h->d_win_over.ensure(n_pairs));
     ORBX_HIP(hipMemsetAsync(h->d_win_over.p, 0, sizeof(int32_t) * n_pairs, s));
     A.win_n = h->d_win_n.p;

@@ -508,6 +508,76 @@ def test_frame_model_batch_and_batched_projection(oracle, test_images, cap):
     mt.close()
 
 
+def test_batched_projection_crowded_windows(oracle):
+    """Windows that hold more acceptable candidates than a pre-sorted list has entries (a cluster of features with
+    near-identical descriptors): those points are resolved by the in-kernel window scan, at their turn in the
+    sequential order, and the result still equals the oracle's."""
+    import torch
+    rng = np.random.default_rng(77)
+    N, cap, B = 700, 768, 2
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    grid = orbx.make_grid(bounds)
+    og = oracle.grid_params(bounds)
+    sf = np.array([1.2 ** l for l in range(8)], np.float32)
+    base_desc = rng.integers(0, 256, (4, 32), dtype=np.uint8)
+    frames = []
+    for f in range(B):
+        k = np.zeros(N, orbx.KP_DTYPE)
+        crowd = 300
+        k["x"][:crowd] = 300 + rng.uniform(0, 24, crowd)
+        k["y"][:crowd] = 200 + rng.uniform(0, 24, crowd)
+        k["x"][crowd:] = rng.uniform(5, 635, N - crowd)
+        k["y"][crowd:] = rng.uniform(5, 440, N - crowd)   # the grid (64 rows of 7 pixels) ends at y = 448
+        k["size"], k["octave"], k["class_id"] = 31.0, 0, -1
+        k["angle"] = rng.uniform(0, 360, N).astype(np.float32)
+        d = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+        d[:crowd] = base_desc[rng.integers(0, 4, crowd)]
+        flip = rng.integers(0, 32, crowd)
+        d[np.arange(crowd), flip] ^= (1 << rng.integers(0, 8, crowd)).astype(np.uint8)   # distances 0..2 inside the crowd
+        k2, start, items = oracle.assign_grid(og, k)
+        assert len(k2) == N                       # all inside the grid: the order is unchanged
+        frames.append((k2, d, start, items))
+    ncell = grid.grid_cols * grid.grid_rows
+    kps = np.zeros((B, cap), orbx.KP_DTYPE)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    cs = np.zeros((B, ncell + 1), np.int32)
+    ci = np.zeros((B, cap), np.int32)
+    for f, (k2, d, start, items) in enumerate(frames):
+        kps[f, :N], desc[f, :N], cs[f], ci[f, :N] = k2, d, start, items
+    counts = np.full(B, N, np.int32)
+    pairs = [(1, 0), (0, 1)]
+    proj = np.zeros((len(pairs), cap, 2), np.float32)
+    for i, (f, r) in enumerate(pairs):
+        proj[i, :N, 0], proj[i, :N, 1] = frames[r][0]["x"], frames[r][0]["y"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+    d_kps, d_desc, d_cnt, d_cs, d_ci, d_proj = t(kps), t(desc), t(counts), t(cs), t(ci), t(proj)
+    d_fi = torch.tensor([a for a, _ in pairs], dtype=torch.int32, device="cuda")
+    d_ri = torch.tensor([b for _, b in pairs], dtype=torch.int32, device="cuda")
+    d_matched = torch.zeros((len(pairs), cap), dtype=torch.int32, device="cuda")
+    d_dist = torch.zeros((len(pairs), cap), dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(len(pairs), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    mt = orbx.Matcher()
+    for radius, orient in ((15.0, False), (30.0, True)):
+        mt.match_projection_frame_batch(grid, len(pairs), d_fi.data_ptr(), d_ri.data_ptr(), d_kps.data_ptr(),
+                                        d_desc.data_ptr(), d_cnt.data_ptr(), cap, d_cs.data_ptr(), d_ci.data_ptr(), 0,
+                                        d_proj.data_ptr(), 0, sf, 0, radius, orient, d_matched.data_ptr(),
+                                        d_dist.data_ptr(), d_nm.data_ptr())
+        torch.cuda.synchronize()
+        hm, hd, hn = d_matched.cpu().numpy(), d_dist.cpu().numpy(), d_nm.cpu().numpy()
+        for i, (f, r) in enumerate(pairs):
+            fk, fd, start, items = frames[f]
+            rk, rd = frames[r][0], frames[r][1]
+            om = oracle.match_projection_frame(og, start, items, fk, fd, rk, np.ones(N, np.uint8), proj[i, :N],
+                                               np.ones(N, np.float32), rd, sf, 0, radius, orient)
+            got_q = np.nonzero(hm[i, :N] > 0)[0]
+            assert hn[i] == len(om) == len(got_q), (i, radius)
+            assert np.array_equal(got_q, om["query"]) and np.array_equal(hm[i, got_q], om["train"])
+            assert np.array_equal(hd[i, got_q].astype(np.float32), om["distance"])
+        assert hn.min() > 50
+    mt.close()
+
+
 def test_wave_parallel_retain_best_matches_libstdcxx(oracle):
     """The wave-parallel nth_element + partition of the device selection leaves the kept responses in the order the
     real libstdc++ calls do: ties, sorted / reversed / constant inputs, and the heap-select fallback."""
