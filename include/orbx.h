@@ -301,7 +301,9 @@ orbx_status orbx_ransac_fh(orbx_ransac* h, const float* points, const float* ref
 
 /* Batched form on device-resident data: pair p uses points d_points + p*n*2 etc.; every pair has n points and
    `iterations` sets.  Outputs are device arrays: d_F/d_H [pairs][9], d_inliers_* [pairs][n], d_scores [pairs][2]
-   (float-rounded scores, F then H), d_best_iteration [pairs][2]. */
+   (float-rounded scores, F then H), d_best_iteration [pairs][2].  The sets are device data, so the call cannot
+   inspect them without waiting for the GPU: a set index >= n is never used as an address, and the pair it belongs
+   to comes back with d_best_iteration -2, score 0 and no inliers (its d_F / d_H rows are left untouched). */
 orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const float* d_ref_points, int n,
                                  const uint32_t* d_sets8, int iterations, int n_pairs, double sigma,
                                  float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,

@@ -9,6 +9,7 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line) 
     std::snprintf(buf, sizeof(buf), "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
     g_last_error = buf;
 }
+void set_last_error_text(const char* text) { g_last_error = text; }
 const std::string& last_error() { return g_last_error; }
 }  // namespace orbx
 

@@ -14,6 +14,7 @@
 namespace orbx {
 
 void set_last_error(const char* what, hipError_t e, const char* file, int line);
+void set_last_error_text(const char* text);
 
 #define ORBX_HIP(expr)                                                   \
     do {                                                                 \

@@ -22,7 +22,7 @@ struct orbx_ransac {
     DevBuf<float> d_pts, d_ref, d_pn, d_rn, d_T, d_Fall, d_Hall, d_Hiall, d_sf, d_sh, d_F, d_H, d_scores;
     DevBuf<uint32_t> d_sets;
     DevBuf<uint8_t> d_inlf, d_inlh;
-    DevBuf<int32_t> d_best;
+    DevBuf<int32_t> d_best, d_bad;
     // pose recovery
     DevBuf<double> d_ppts, d_pref, d_cand, d_norm, d_R, d_t, d_xyz;
     DevBuf<float> d_K, d_Fp;
@@ -33,10 +33,16 @@ struct orbx_ransac {
 
 namespace {
 
-orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref, int n, const uint32_t* d_sets8,
-                      int iterations, int pairs, double sigma, float* d_F, float* d_H, uint8_t* d_inl_f,
-                      uint8_t* d_inl_h, float* d_scores, int32_t* d_best) {
-    hipStream_t s = h->stream;
+// Intermediate device arrays of one batch: normalised points [pairs][n][2] x2, T [pairs][2][9], hypotheses
+// [pairs][iterations][9] x3, scores [pairs][iterations] x2, and one word per pair that k_solve_f raises when a set
+// names a correspondence that does not exist (it must be zero when the batch starts).
+struct Workspace {
+    float *pn, *rn, *T, *Fall, *Hall, *Hiall, *sf, *sh;
+    int32_t* bad;
+};
+
+// The handle's own (growing) buffers as the workspace of a batch.
+orbx_status handle_workspace(orbx_ransac* h, int n, int iterations, int pairs, Workspace* w) {
     const size_t pn = (size_t)pairs * n * 2, hyp = (size_t)pairs * iterations;
     ORBX_TRY(h->d_pn.ensure(pn));
     ORBX_TRY(h->d_rn.ensure(pn));
@@ -46,10 +52,21 @@ orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref,
     ORBX_TRY(h->d_Hiall.ensure(hyp * 9));
     ORBX_TRY(h->d_sf.ensure(hyp));
     ORBX_TRY(h->d_sh.ensure(hyp));
+    ORBX_TRY(h->d_bad.ensure(pairs));
+    *w = Workspace{h->d_pn.p, h->d_rn.p, h->d_T.p, h->d_Fall.p, h->d_Hall.p, h->d_Hiall.p, h->d_sf.p, h->d_sh.p,
+                   h->d_bad.p};
+    return ORBX_OK;
+}
+
+orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points, const float* d_ref, int n,
+                      const uint32_t* d_sets8, int iterations, int pairs, double sigma, float* d_F, float* d_H,
+                      uint8_t* d_inl_f, uint8_t* d_inl_h, float* d_scores, int32_t* d_best) {
+    hipStream_t s = h->stream;
+    ORBX_HIP(hipMemsetAsync(w.bad, 0, sizeof(int32_t) * pairs, s));
     StageTimer& T = h->timer;
     T.clear();
     T.begin(RT_NORMALIZE, s);
-    hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, h->d_pn.p, h->d_rn.p, h->d_T.p);
+    hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, w.pn, w.rn, w.T);
     T.end(RT_NORMALIZE, s);
     const int hyp_blocks64 = (int)(((long long)pairs * iterations + 63) / 64);
     // a 256-hypothesis workgroup spans at most kScorePairs pairs when iterations >= 86; below that, one launch
@@ -62,38 +79,38 @@ orbx_status run_batch(orbx_ransac* h, const float* d_points, const float* d_ref,
     ORBX_HIP(hipEventRecord(h->ev_fork, s));
     ORBX_HIP(hipStreamWaitEvent(sh, h->ev_fork, 0));
     T.begin(RT_SOLVE, s);
-    hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
-                       iterations, pairs, h->d_Fall.p);
+    hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, w.pn, w.rn, n, w.T, d_sets8,
+                       iterations, pairs, w.Fall, w.bad);
     T.end(RT_SOLVE, s);
     T.begin(RT_SCORE_H, sh);
-    hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, sh, h->d_pn.p, h->d_rn.p, n, h->d_T.p, d_sets8,
-                       iterations, pairs, h->d_Hall.p, h->d_Hiall.p);
+    hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, sh, w.pn, w.rn, n, w.T, d_sets8,
+                       iterations, pairs, w.Hall, w.Hiall);
     T.begin(RT_SCORE_F, s);
     if (flat)
-        hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, iterations,
-                           pairs, sigma, h->d_sf.p);
+        hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, w.Fall, iterations,
+                           pairs, sigma, w.sf);
     else
         for (int p = 0; p < pairs; p++)
             hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points + (size_t)p * n * 2,
-                               d_ref + (size_t)p * n * 2, n, h->d_Fall.p + (size_t)p * iterations * 9, iterations, 1,
-                               sigma, h->d_sf.p + (size_t)p * iterations);
+                               d_ref + (size_t)p * n * 2, n, w.Fall + (size_t)p * iterations * 9, iterations, 1,
+                               sigma, w.sf + (size_t)p * iterations);
     T.end(RT_SCORE_F, s);
     if (flat)
-        hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points, d_ref, n, h->d_Hall.p,
-                           h->d_Hiall.p, iterations, pairs, sigma, h->d_sh.p);
+        hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points, d_ref, n, w.Hall,
+                           w.Hiall, iterations, pairs, sigma, w.sh);
     else
         for (int p = 0; p < pairs; p++)
             hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points + (size_t)p * n * 2,
-                               d_ref + (size_t)p * n * 2, n, h->d_Hall.p + (size_t)p * iterations * 9,
-                               h->d_Hiall.p + (size_t)p * iterations * 9, iterations, 1, sigma,
-                               h->d_sh.p + (size_t)p * iterations);
+                               d_ref + (size_t)p * n * 2, n, w.Hall + (size_t)p * iterations * 9,
+                               w.Hiall + (size_t)p * iterations * 9, iterations, 1, sigma,
+                               w.sh + (size_t)p * iterations);
     T.end(RT_SCORE_H, sh);
     ORBX_HIP(hipEventRecord(h->ev_join, sh));
     ORBX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     T.begin(RT_SELECT, s);
-    hipLaunchKernelGGL(k_select, dim3(pairs, 2), dim3(256), 0, s, d_points, d_ref, n, h->d_Fall.p, h->d_Hall.p,
-                       h->d_Hiall.p, h->d_sf.p, h->d_sh.p, iterations, sigma, d_F, d_H, d_inl_f, d_inl_h, d_scores,
-                       d_best);
+    hipLaunchKernelGGL(k_select, dim3(pairs, 2), dim3(256), 0, s, d_points, d_ref, n, w.Fall, w.Hall,
+                       w.Hiall, w.sf, w.sh, w.bad, iterations, sigma, d_F, d_H, d_inl_f, d_inl_h,
+                       d_scores, d_best);
     T.end(RT_SELECT, s);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -153,7 +170,7 @@ void orbx_ransac_destroy(orbx_ransac* h) {
     h->d_pts.release(); h->d_ref.release(); h->d_pn.release(); h->d_rn.release(); h->d_T.release();
     h->d_Fall.release(); h->d_Hall.release(); h->d_Hiall.release(); h->d_sf.release(); h->d_sh.release();
     h->d_F.release(); h->d_H.release(); h->d_scores.release(); h->d_sets.release(); h->d_inlf.release();
-    h->d_inlh.release(); h->d_best.release();
+    h->d_inlh.release(); h->d_best.release(); h->d_bad.release();
     h->d_ppts.release(); h->d_pref.release(); h->d_cand.release(); h->d_norm.release(); h->d_R.release();
     h->d_t.release(); h->d_xyz.release(); h->d_K.release(); h->d_Fp.release(); h->d_pstart.release();
     h->d_good.release(); h->d_count.release();
@@ -188,7 +205,9 @@ orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const fl
         return ORBX_BAD_ARG;
     if (n < 8 || iterations <= 0 || n_pairs <= 0 || !(sigma > 0)) return ORBX_BAD_ARG;
     ORBX_HIP(hipSetDevice(h->device));
-    return run_batch(h, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H, d_inliers_f,
+    Workspace w;
+    ORBX_TRY(handle_workspace(h, n, iterations, n_pairs, &w));
+    return run_batch(h, w, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H, d_inliers_f,
                      d_inliers_h, d_scores, d_best_iteration);
 }
 
@@ -209,7 +228,9 @@ orbx_status orbx_ransac_fh(orbx_ransac* h, const float* points, const float* ref
     ORBX_TRY(h->d_inlh.ensure(n));
     ORBX_TRY(h->d_scores.ensure(2));
     ORBX_TRY(h->d_best.ensure(2));
-    ORBX_TRY(run_batch(h, h->d_pts.p, h->d_ref.p, n, h->d_sets.p, iterations, 1, sigma, h->d_F.p, h->d_H.p,
+    Workspace w;
+    ORBX_TRY(handle_workspace(h, n, iterations, 1, &w));
+    ORBX_TRY(run_batch(h, w, h->d_pts.p, h->d_ref.p, n, h->d_sets.p, iterations, 1, sigma, h->d_F.p, h->d_H.p,
                        h->d_inlf.p, h->d_inlh.p, h->d_scores.p, h->d_best.p));
     float hF[9], hH[9], sc[2];
     int32_t best[2];
@@ -244,7 +265,9 @@ orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float*
     ORBX_TRY(h->d_inlh.ensure(n));
     ORBX_TRY(h->d_scores.ensure(2));
     ORBX_TRY(h->d_best.ensure(2));
-    ORBX_TRY(run_batch(h, h->d_pts.p, h->d_ref.p, n, h->d_sets.p, iterations, 1, sigma, h->d_F.p, h->d_H.p,
+    Workspace w;
+    ORBX_TRY(handle_workspace(h, n, iterations, 1, &w));
+    ORBX_TRY(run_batch(h, w, h->d_pts.p, h->d_ref.p, n, h->d_sets.p, iterations, 1, sigma, h->d_F.p, h->d_H.p,
                        h->d_inlf.p, h->d_inlh.p, h->d_scores.p, h->d_best.p));
     const size_t m = (size_t)iterations * 9 * sizeof(float);
     if (F_all) ORBX_HIP(hipMemcpyAsync(F_all, h->d_Fall.p, m, hipMemcpyDeviceToHost, s));

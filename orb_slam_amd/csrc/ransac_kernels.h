@@ -327,7 +327,8 @@ __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts,
 // (Initializer.cpp:336-345).
 __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
                                                 const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
-                                                int iterations, int pairs, float* __restrict__ F_all) {
+                                                int iterations, int pairs, float* __restrict__ F_all,
+                                                int32_t* __restrict__ bad_sets) {
     // hypotheses of all pairs are numbered through, so wavefronts stay full when `iterations` is no multiple of 64
     const long long hyp = (long long)blockIdx.x * 64 + threadIdx.x;
     if (hyp >= (long long)pairs * iterations) return;
@@ -336,10 +337,14 @@ __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n,
     const float* rn = ref_n + (size_t)pair * n * 2;
     const uint32_t* set = sets8 + ((size_t)pair * iterations + it) * 8;
     // 8x9 system used as is (rows = equations): N = 8 rows of length M = 9, completed to 9 rows
+    // a set that names a correspondence outside [0, n) must not become an address: its index is replaced by 0 and
+    // the pair is flagged, and k_select then reports the pair as invalid instead of a winner
     float At[81];
+    bool bad = false;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint32_t idx = set[i];
+        uint32_t idx = set[i];
+        if (idx >= (uint32_t)n) { idx = 0; bad = true; }
         const float u2 = pn[2 * idx], v2 = pn[2 * idx + 1], u1 = rn[2 * idx], v1 = rn[2 * idx + 1];
         At[i * 9 + 0] = u2 * u1; At[i * 9 + 1] = u2 * v1; At[i * 9 + 2] = u2;
         At[i * 9 + 3] = v2 * u1; At[i * 9 + 4] = v2 * v1; At[i * 9 + 5] = v2;
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n,
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) At[72 + k] = 0.f;
+    if (bad) bad_sets[pair] = 1;
     {
         float(&A8)[72] = *reinterpret_cast<float(*)[72]>(&At[0]);
         float no_v[1];
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n,
 
 // K11H: one hypothesis per lane.  geometry::computeHomographyMat (utils.cpp:112-154), then the de-normalisation,
 // inverse and scaling of Initializer::findHomographyMat (Initializer.cpp:476-486).
-__global__ __launch_bounds__(64) void k_solve_h(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_solve_h(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
                                                 const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
                                                 int iterations, int pairs, float* __restrict__ H_all,
                                                 float* __restrict__ Hinv_all) {
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(64) void k_solve_h(const float* __restrict__ pts_n,
     int perm[9];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint32_t idx = set[i];
+        uint32_t idx = set[i];
+        if (idx >= (uint32_t)n) idx = 0;  // k_solve_f flags the pair
         const float u2 = pn[2 * idx], v2 = pn[2 * idx + 1], u1 = rn[2 * idx], v1 = rn[2 * idx + 1];
         const int c0 = 2 * i, c1 = 2 * i + 1;
         At[0 * 16 + c0] = 0.0f; At[1 * 16 + c0] = 0.0f; At[2 * 16 + c0] = 0.0f;
@@ -572,14 +579,16 @@ __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, 
     if (live) score_out[(size_t)sp.pair * iterations + sp.it] = score;
 }
 
-// Winner selection and inlier flags.  The reference keeps a hypothesis when (float)score > best (strict), best
+// Winner selection and inlier flags (best_out: winning iteration, -1 when no hypothesis scored above 0, -2 when
+// one of the pair's sets held an index >= n).  The reference keeps a hypothesis when (float)score > best (strict), best
 // starting at 0: the winner is the earliest iteration that reaches the maximum, provided the maximum is > 0
 // (Initializer.cpp:318,347-355,458,488-497).  grid = (pairs, 2): y = 0 fundamental, y = 1 homography.
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ pts, const float* __restrict__ ref, int n,
                                                 const float* __restrict__ F_all, const float* __restrict__ H_all,
                                                 const float* __restrict__ Hinv_all,
                                                 const float* __restrict__ score_f, const float* __restrict__ score_h,
-                                                int iterations, double sigma, float* __restrict__ F_out,
+                                                const int32_t* __restrict__ bad_sets, int iterations, double sigma,
+                                                float* __restrict__ F_out,
                                                 float* __restrict__ H_out, uint8_t* __restrict__ inl_f,
                                                 uint8_t* __restrict__ inl_h, float* __restrict__ scores_out,
                                                 int32_t* __restrict__ best_out) {
@@ -606,7 +615,8 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ pts, c
         }
         __syncthreads();
     }
-    const int best = s_it[0];
+    // a pair whose sets were invalid has no winner: best iteration -2, score 0, no inliers
+    const int best = bad_sets[pair] ? -2 : s_it[0];
     const float best_score = s_val[0];
     if (tid == 0) {
         best_out[pair * 2 + model] = best;

@@ -413,6 +413,24 @@ def test_ransac_batch_equals_single(oracle, ransac):
         assert np.array_equal(d_if[p].cpu().numpy(), o["inliers_f"])
         assert np.array_equal(d_ih[p].cpu().numpy(), o["inliers_h"])
         assert d_sc[p, 0].item() == o["score_f"] and d_sc[p, 1].item() == o["score_h"]
+    # device-resident sets cannot be inspected by the call: an index that names no correspondence is never used as
+    # an address, its pair comes back as invalid (-2, score 0, no inliers, matrices untouched), the others as before
+    bad = sets.copy()
+    bad[2, 17, 5] = n
+    bad[2, 100, 0] = 0xFFFFFFF0
+    d_bad = torch.from_numpy(bad.astype(np.int64)).to(torch.int32).cuda()
+    want = [t.clone() for t in (d_F, d_H, d_if, d_ih, d_sc, d_best)]
+    d_F[2] = -5.0
+    d_H[2] = -5.0
+    torch.cuda.synchronize()
+    ransac.fh_batch(d_pts.data_ptr(), d_ref.data_ptr(), n, d_bad.data_ptr(), it, P, 1.0, d_F.data_ptr(),
+                    d_H.data_ptr(), d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_best.data_ptr())
+    torch.cuda.synchronize()
+    keep = [p for p in range(P) if p != 2]
+    for got, exp in zip((d_F, d_H, d_if, d_ih, d_sc, d_best), want):
+        assert torch.equal(got[keep], exp[keep])
+    assert (d_best[2] == -2).all() and (d_sc[2] == 0).all() and not d_if[2].any() and not d_ih[2].any()
+    assert (d_F[2] == -5.0).all() and (d_H[2] == -5.0).all()
 
 
 @pytest.mark.parametrize("cap", [1280, 6500])
