@@ -309,6 +309,20 @@ orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const fl
                                  float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,
                                  float* d_scores, int32_t* d_best_iteration);
 
+/* orbx_ransac_fh_batch for callers that cannot allocate device memory while they run (code under HIP graph capture,
+   tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+   results bit for bit; the intermediate arrays (normalised points, every hypothesis and its score) live in a
+   fixed device array of about 5.9 MB that each GPU the library runs on holds until the process ends, and the call
+   makes no hipMalloc / hipFree.  Limits per call: n_pairs <= 1024, n_pairs * iterations <= 32768,
+   n_pairs * n <= 131072; beyond them ORBX_CAPACITY is returned (orbx_last_error() names the limits) and nothing
+   runs.  Every call on a GPU shares that GPU's array, whichever handle it goes through: calls that overlap on one
+   GPU race, so run them one after the other (one stream, or an event between them).  The array keeps the last
+   call's contents; the call clears the words that must start at zero itself. */
+orbx_status orbx_ransac_fh_batch_static(orbx_ransac* h, const float* d_points, const float* d_ref_points, int n,
+                                        const uint32_t* d_sets8, int iterations, int n_pairs, double sigma,
+                                        float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,
+                                        float* d_scores, int32_t* d_best_iteration);
+
 /* Per-hypothesis probe for the parity tests: all hypotheses and scores of one pair (host arrays, iterations
    rows): F_all/H_all/Hinv_all [it][9], score_f/score_h [it]. */
 orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float* ref_points, int n,

@@ -2,6 +2,7 @@
 // Replaces Initializer::findFundamentalAndHomography and its callees (reference src/Initializer.cpp:254-585,
 // src/geometry/utils.cpp:18-154).
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "ransac_kernels.h"
@@ -19,6 +20,7 @@ struct orbx_ransac {
     // the homography chain runs beside the fundamental chain (the reference uses two threads, Initializer.cpp:291-303)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned char* static_scratch = nullptr;  // this GPU's copy of the file-scope workspace
     DevBuf<float> d_pts, d_ref, d_pn, d_rn, d_T, d_Fall, d_Hall, d_Hiall, d_sf, d_sh, d_F, d_H, d_scores;
     DevBuf<uint32_t> d_sets;
     DevBuf<uint8_t> d_inlf, d_inlh;
@@ -116,6 +118,46 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
     return ORBX_OK;
 }
 
+// ---- workspace of the entry point that allocates nothing ------------------------------------------------------
+// One file-scope device array per GPU holds what handle_workspace() would otherwise allocate.  Limits of a call:
+constexpr size_t kStaticMaxHyp = 32768;      // n_pairs * iterations
+constexpr size_t kStaticMaxPoints = 131072;  // n_pairs * n
+constexpr size_t kStaticMaxPairs = 1024;
+constexpr size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t kOffPn = 0;
+constexpr size_t kOffRn = kOffPn + align256(kStaticMaxPoints * 2 * sizeof(float));
+constexpr size_t kOffT = kOffRn + align256(kStaticMaxPoints * 2 * sizeof(float));
+constexpr size_t kOffFall = kOffT + align256(kStaticMaxPairs * 18 * sizeof(float));
+constexpr size_t kOffHall = kOffFall + align256(kStaticMaxHyp * 9 * sizeof(float));
+constexpr size_t kOffHiall = kOffHall + align256(kStaticMaxHyp * 9 * sizeof(float));
+constexpr size_t kOffSf = kOffHiall + align256(kStaticMaxHyp * 9 * sizeof(float));
+constexpr size_t kOffSh = kOffSf + align256(kStaticMaxHyp * sizeof(float));
+constexpr size_t kOffBad = kOffSh + align256(kStaticMaxHyp * sizeof(float));
+constexpr size_t kScratchBytes = kOffBad + align256(kStaticMaxPairs * sizeof(int32_t));  // about 5.9 MB
+
+// Every GPU the library runs on holds its own copy of this array until the process ends.  In host code the name
+// is only a handle for hipGetSymbolAddress: the device address it yields (one per GPU) is what kernels and
+// hipMemsetAsync receive.
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on `device` (which must be the current device); looked up once per device.
+orbx_status resolve_scratch(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return ORBX_BAD_ARG;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        unsigned char* ptr = nullptr;
+        ORBX_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return ORBX_DEVICE;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return ORBX_OK;
+}
+
 orbx_status check_sets(const uint32_t* sets8, int iterations, int n) {
     for (size_t i = 0; i < (size_t)iterations * 8; i++)
         if (sets8[i] >= (uint32_t)n) return ORBX_BAD_ARG;
@@ -155,6 +197,7 @@ orbx_status orbx_ransac_create(int device, orbx_ransac** out) {
         return ORBX_DEVICE;
     }
     orbx_status st = h->timer.init();
+    if (st == ORBX_OK) st = resolve_scratch(device, &h->static_scratch);
     if (st != ORBX_OK) {
         orbx_ransac_destroy(h);
         return st;
@@ -207,6 +250,33 @@ orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const fl
     ORBX_HIP(hipSetDevice(h->device));
     Workspace w;
     ORBX_TRY(handle_workspace(h, n, iterations, n_pairs, &w));
+    return run_batch(h, w, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H, d_inliers_f,
+                     d_inliers_h, d_scores, d_best_iteration);
+}
+
+orbx_status orbx_ransac_fh_batch_static(orbx_ransac* h, const float* d_points, const float* d_ref_points, int n,
+                                        const uint32_t* d_sets8, int iterations, int n_pairs, double sigma,
+                                        float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,
+                                        float* d_scores, int32_t* d_best_iteration) {
+    if (!h || !d_points || !d_ref_points || !d_sets8 || !d_F || !d_H || !d_inliers_f || !d_inliers_h || !d_scores ||
+        !d_best_iteration)
+        return ORBX_BAD_ARG;
+    if (n < 8 || iterations <= 0 || n_pairs <= 0 || !(sigma > 0)) return ORBX_BAD_ARG;
+    if ((size_t)n_pairs > kStaticMaxPairs || (size_t)n_pairs * iterations > kStaticMaxHyp ||
+        (size_t)n_pairs * n > kStaticMaxPoints) {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg),
+                      "orbx_ransac_fh_batch_static: %d pairs x %d iterations x %d correspondences exceed the fixed "
+                      "workspace (at most %zu pairs, %zu hypotheses and %zu correspondences per call)",
+                      n_pairs, iterations, n, kStaticMaxPairs, kStaticMaxHyp, kStaticMaxPoints);
+        set_last_error_text(msg);
+        return ORBX_CAPACITY;
+    }
+    ORBX_HIP(hipSetDevice(h->device));
+    unsigned char* base = h->static_scratch;
+    const Workspace w{(float*)(base + kOffPn),   (float*)(base + kOffRn),    (float*)(base + kOffT),
+                      (float*)(base + kOffFall), (float*)(base + kOffHall),  (float*)(base + kOffHiall),
+                      (float*)(base + kOffSf),   (float*)(base + kOffSh),    (int32_t*)(base + kOffBad)};
     return run_batch(h, w, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H, d_inliers_f,
                      d_inliers_h, d_scores, d_best_iteration);
 }

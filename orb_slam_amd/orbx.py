@@ -25,7 +25,7 @@ SYMBOLS = [
     "orbx_extractor_last_timings", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_match_hamming",
     "orbx_match_hamming_batch", "orbx_filter_matches", "orbx_match_radius", "orbx_assign_grid",
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
-    "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
+    "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_batch_static", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
     "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_match_bow_batch", "orbx_match_epipolar_batch", "orbx_recover_pose_batch", "orbx_triangulate_batch",
     "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
@@ -637,6 +637,15 @@ class Ransac:
                                           iterations, n_pairs, C.c_double(sigma), C.c_void_p(d_F), C.c_void_p(d_H),
                                           C.c_void_p(d_inl_f), C.c_void_p(d_inl_h), C.c_void_p(d_scores),
                                           C.c_void_p(d_best)), "orbx_ransac_fh_batch")
+
+    def fh_batch_static(self, d_pts, d_ref, n, d_sets, iterations, n_pairs, sigma, d_F, d_H, d_inl_f, d_inl_h,
+                        d_scores, d_best):
+        """orbx_ransac_fh_batch_static: the same batch through the library's fixed device workspace (no allocation)."""
+        _check(lib().orbx_ransac_fh_batch_static(self._h, C.c_void_p(d_pts), C.c_void_p(d_ref), n,
+                                                 C.c_void_p(d_sets), iterations, n_pairs, C.c_double(sigma),
+                                                 C.c_void_p(d_F), C.c_void_p(d_H), C.c_void_p(d_inl_f),
+                                                 C.c_void_p(d_inl_h), C.c_void_p(d_scores), C.c_void_p(d_best)),
+               "orbx_ransac_fh_batch_static")
 
     def last_timings(self):
         ms = np.zeros(5, np.float32)
