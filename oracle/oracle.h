@@ -52,6 +52,14 @@ typedef struct {
     int32_t gray_variant;   /* 0: 14-bit (1868,9617,4899)  1: 15-bit (3735,19235,9798) */
     int32_t resize_variant; /* 0: INTER_LINEAR_EXACT       1: legacy INTER_LINEAR */
     int32_t retain_variant; /* 0: nth_element at n-1       1: nth_element at n (older OpenCV) */
+    /* descriptor-stage switches; 0 everywhere is the behaviour the HIP path reproduces, the others exist to measure
+       how far each open question about the reference's OpenCV build could move the descriptors */
+    int32_t blur_variant;   /* 0: 8-bit fixed-point separable kernel (generic filter engine)
+                               1: float separable kernel, one rounding at the end (what an IPP-backed build computes,
+                                  up to its own rounding)   2: variant 1 on level 0 only (IPP is only picked for
+                                  images large enough to be split over threads) */
+    int32_t round_variant;  /* 0: cvRound = nearest-even (SSE2 build)  1: floor(v + 0.5) (the portable fallback) */
+    float   blur_sigma;     /* 0 = 2.0 (orb.cpp) */
 } orc_orb_params;
 
 /* ---- extraction ---- */

@@ -495,9 +495,22 @@ void detect_impl(const orc_orb_params* p, const uint8_t* img, int w, int h, int 
 
 /* imgproc smooth.cpp GaussianBlur(7x7, sigma 2) on an 8-bit sub-matrix without BORDER_ISOLATED:
    generic separable path with the symmetric 8-bit fixed-point kernel (getGaussianKernel -> x256 rounded). */
-void gaussian_kernel_q8(int k[7]) {
+void gaussian_kernel_f32(float cf[7], double sigma) {
     const int n = 7;
-    const double sigma = 2.0;
+    double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = std::exp(scale2x * x * x);
+        cf[i] = (float)t;
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) cf[i] = (float)(cf[i] * sum);
+}
+
+void gaussian_kernel_q8(int k[7], double sigma) {
+    const int n = 7;
     double scale2x = -0.5 / (sigma * sigma);
     float cf[7];
     double sum = 0;
@@ -514,12 +527,42 @@ void gaussian_kernel_q8(int k[7]) {
     }
 }
 
-void blur_levels(const Layout& L, uint8_t* atlas) {
+/* Investigation variant only (blur_variant 1/2): the same kernel applied in float, rounded once. */
+void blur_level_float(const Rect& r, int aw, uint8_t* atlas, double sigma) {
+    float kf[7];
+    gaussian_kernel_f32(kf, sigma);
+    std::vector<float> tmp((size_t)(r.h + 6) * r.w);
+    for (int y = -3; y < r.h + 3; y++) {
+        const uint8_t* s = atlas + (size_t)(r.y + y) * aw + r.x;
+        float* t = &tmp[(size_t)(y + 3) * r.w];
+        for (int x = 0; x < r.w; x++) {
+            float acc = 0;
+            for (int i = 0; i < 7; i++) acc += kf[i] * s[x + i - 3];
+            t[x] = acc;
+        }
+    }
+    for (int y = 0; y < r.h; y++) {
+        uint8_t* d = atlas + (size_t)(r.y + y) * aw + r.x;
+        for (int x = 0; x < r.w; x++) {
+            float acc = 0;
+            for (int i = 0; i < 7; i++) acc += kf[i] * tmp[(size_t)(y + i) * r.w + x];
+            int v = cv_roundf(acc);
+            d[x] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+    }
+}
+
+void blur_levels(const orc_orb_params* p, const Layout& L, uint8_t* atlas) {
+    const double sigma = p->blur_sigma > 0 ? (double)p->blur_sigma : 2.0;
     int kq[7];
-    gaussian_kernel_q8(kq);
+    gaussian_kernel_q8(kq, sigma);
     int aw = L.atlas_w;
     for (size_t level = 0; level < L.rect.size(); level++) {
         const Rect& r = L.rect[level];
+        if (p->blur_variant == 1 || (p->blur_variant == 2 && level == 0)) {
+            blur_level_float(r, aw, atlas, sigma);
+            continue;
+        }
         /* row pass over rows y-3..y+3 of the un-blurred atlas (its border already holds reflect-101 data) */
         std::vector<int> tmp((size_t)(r.h + 6) * r.w);
         for (int y = -3; y < r.h + 3; y++) {
@@ -544,8 +587,10 @@ void blur_levels(const Layout& L, uint8_t* atlas) {
 }
 
 /* orb.cpp computeOrbDescriptors(), WTA_K == 2 */
+inline int round_as(float v, int variant) { return variant == 0 ? cv_roundf(v) : (int)std::floor((double)v + 0.5); }
+
 void orb_descriptors(const uint8_t* atlas, int step, const Layout& L, const std::vector<orc_keypoint>& kps,
-                     uint8_t* desc) {
+                     uint8_t* desc, int rv) {
     for (size_t j = 0; j < kps.size(); j++) {
         const orc_keypoint& kpt = kps[j];
         const Rect& layer = L.rect[kpt.octave];
@@ -553,8 +598,8 @@ void orb_descriptors(const uint8_t* atlas, int step, const Layout& L, const std:
         float angle = kpt.angle;
         angle *= (float)(M_PI / 180.f);
         float a = (float)cos((double)angle), b = (float)sin((double)angle);
-        const uint8_t* center = atlas + (size_t)(cv_roundf(kpt.y * scale) + layer.y) * step +
-                                cv_roundf(kpt.x * scale) + layer.x;
+        const uint8_t* center = atlas + (size_t)(round_as(kpt.y * scale, rv) + layer.y) * step +
+                                round_as(kpt.x * scale, rv) + layer.x;
         const int* pat = kBitPattern31;
         uint8_t* d = desc + j * 32;
         for (int i = 0; i < 32; i++, pat += 32) {
@@ -563,8 +608,8 @@ void orb_descriptors(const uint8_t* atlas, int step, const Layout& L, const std:
                 const int* q = pat + bit * 4;
                 float x0 = q[0] * a - q[1] * b, y0 = q[0] * b + q[1] * a;
                 float x1 = q[2] * a - q[3] * b, y1 = q[2] * b + q[3] * a;
-                int t0 = center[cv_roundf(y0) * step + cv_roundf(x0)];
-                int t1 = center[cv_roundf(y1) * step + cv_roundf(x1)];
+                int t0 = center[round_as(y0, rv) * step + round_as(x0, rv)];
+                int t1 = center[round_as(y1, rv) * step + round_as(x1, rv)];
                 val |= (t0 < t1) << bit;
             }
             d[i] = (uint8_t)val;
@@ -608,7 +653,7 @@ void orc_orb_pyramid(const orc_orb_params* p, const uint8_t* img, int w, int h, 
 
 void orc_orb_blur(const orc_orb_params* p, int w, int h, int nlevels, uint8_t* atlas) {
     Layout L = make_layout(p, w, h, nlevels);
-    blur_levels(L, atlas);
+    blur_levels(p, L, atlas);
 }
 
 void orc_fast_scores(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* scores) {
@@ -670,8 +715,8 @@ int orc_orb_compute(const orc_orb_params* p, const uint8_t* img, int w, int h, i
         for (auto& v : by_level) k.insert(k.end(), v.begin(), v.end());
     }
     if (k.empty()) return 0;
-    blur_levels(L, atlas.data());
-    orb_descriptors(atlas.data(), L.atlas_w, L, k, desc);
+    blur_levels(p, L, atlas.data());
+    orb_descriptors(atlas.data(), L.atlas_w, L, k, desc, p->round_variant);
     std::copy(k.begin(), k.end(), kps);
     return (int)k.size();
 }

@@ -21,7 +21,8 @@ class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
                 ("patch_size", C.c_int32), ("fast_threshold", C.c_int32), ("gray_variant", C.c_int32),
-                ("resize_variant", C.c_int32), ("retain_variant", C.c_int32)]
+                ("resize_variant", C.c_int32), ("retain_variant", C.c_int32), ("blur_variant", C.c_int32),
+                ("round_variant", C.c_int32), ("blur_sigma", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -63,9 +64,9 @@ def _p(a):
 
 
 def orb_params(nfeatures=1000, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=20,
-               gray_variant=0, resize_variant=0, retain_variant=0):
+               gray_variant=0, resize_variant=0, retain_variant=0, blur_variant=0, round_variant=0, blur_sigma=0.0):
     return OrbParams(nfeatures, scale_factor, nlevels, edge_threshold, 0, 2, 31, fast_threshold,
-                     gray_variant, resize_variant, retain_variant)
+                     gray_variant, resize_variant, retain_variant, blur_variant, round_variant, blur_sigma)
 
 
 def _img(img):

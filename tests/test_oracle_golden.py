@@ -65,30 +65,65 @@ def test_undistorted_bounds_reference_kat(oracle):
     assert abs(b[2] - 14.684) < 1e-3 and abs(b[3] - 473.324) < 1e-3
 
 
-def test_radius_matcher_reference_ranges(oracle, test_images):
-    # src/tests/geometry/orb_matcher_tests.cpp:39-53.  The >= 4500 bound and the zero-duplicates property hold.
-    # The 750..800 window for the filtered count is not met by the mean-absolute-difference distance this matcher
-    # computes today (1140 here); it is met when the distance is the Hamming distance: see the next test.
-    p = _params(oracle, nfeatures=8000)
+def _radius_matcher_kat(oracle, test_images, **variant):
+    """The call sequence of src/tests/geometry/orb_matcher_tests.cpp:22-41 on the oracle."""
+    p = _params(oracle, nfeatures=8000, **variant)
     r = []
     for img in test_images:
         k = oracle.detect(p, img)
         r.append(oracle.compute(p, img, k))
     m = oracle.match_radius(r[0][0], r[1][0], r[0][1], r[1][1], 100.0)
-    assert len(m) >= 4500
     f = oracle.filter_matches(m, len(r[0][1]))
-    assert len(set(f["train"].tolist())) == len(f)
-    assert 500 <= len(f) <= 1500
+    return r, m, f
+
+
+def test_radius_matcher_reference_ranges(oracle, test_images):
+    # orb_matcher_tests.cpp:39 (>= 4500 matches before the filter) and :46-53 (no duplicate trainIdx after it)
+    r, m, f = _radius_matcher_kat(oracle, test_images)
+    assert len(m) >= 4500
+    dup = sum(1 for i in range(len(f)) for j in range(len(f)) if j != i and f["train"][i] == f["train"][j])
+    assert dup == 0
+
+
+@pytest.mark.xfail(strict=True, reason="the oracle's descriptors give 1140 filtered matches where the reference's "
+                   "test expects 750..800; no variant of the descriptor stage that an OpenCV 3.4.9 build could "
+                   "plausibly compute moves the count into the window (test_descriptor_variants_do_not_close_the_gap)")
+def test_filtered_match_count_reference_kat(oracle, test_images):
+    # orb_matcher_tests.cpp:38-41, the assertion exactly as the reference wrote it:
+    #   orb_matcher.match(key_points_1, key_points_2, d_1, d_2, matches, false);   (the radius matcher, :695-712)
+    #   orb_matcher.filterMatches(d_1, matches);
+    #   EXPECT_TRUE((matches.size() >= 750) && (matches.size() <= 800));
+    r, m, f = _radius_matcher_kat(oracle, test_images)
+    assert 750 <= len(f) <= 800
+
+
+def test_filtered_match_count_is_what_was_measured(oracle, test_images):
+    # the number behind the strict xfail above, pinned so that a change of the descriptor stage shows up here
+    r, m, f = _radius_matcher_kat(oracle, test_images)
+    assert len(f) == 1140
+
+
+def test_descriptor_variants_do_not_close_the_gap(oracle, test_images):
+    """What the open questions about the reference's OpenCV build could change in the descriptor stage, measured on
+    the reference's own assertion (750..800 after the radius matcher + filterMatches).  A Gaussian applied in float
+    with one rounding (an IPP-backed build; on every level, or on level 0 only, which is the only level large enough
+    for IPP's threaded path), cvRound as floor(v + 0.5) instead of nearest-even, the 15-bit gray coefficients: each
+    moves the count by at most a few per cent and never below 1139.  Only a different blur STRENGTH moves it far
+    (sigma 1.5 -> 1000, sigma 1 -> 764), and cv::ORB hard-codes sigma 2."""
+    counts = {}
+    for name, kw in (("float_blur", dict(blur_variant=1)), ("float_blur_level0", dict(blur_variant=2)),
+                     ("round_half_up", dict(round_variant=1)), ("gray15", dict(gray_variant=1)),
+                     ("sigma1.5", dict(blur_sigma=1.5)), ("sigma1", dict(blur_sigma=1.0))):
+        counts[name] = len(_radius_matcher_kat(oracle, test_images, **kw)[2])
+    assert counts == {"float_blur": 1163, "float_blur_level0": 1153, "round_half_up": 1140, "gray15": 1139,
+                      "sigma1.5": 1000, "sigma1": 764}
 
 
 def test_filtered_match_window_under_hamming_distance(oracle, test_images):
-    # src/tests/geometry/orb_matcher_tests.cpp:41 expects 750..800 matches after ORBMatcher::filterMatches, whose rule
-    # max(2 * min, 30) (orb_matcher.cpp:905) is the usual one for Hamming distances.  With the Hamming path of the
-    # reference, ORBMatcher::match(descriptors, ref_descriptors, matches, true) = cv::BFMatcher + filterMatches
-    # (orb_matcher.cpp:719-733), the oracle's descriptors of the two test images give 776: inside the window.  The
-    # window discriminates the descriptor stage: the same count is 665 with a blur of sigma 1.5 and 845 with 2.5
-    # (464 / 872 at sigma 1 / 3), so blur strength, steering and sampling pattern are consistent with what the
-    # reference's authors measured on OpenCV's own descriptors.
+    # The same window IS met when the distance is the Hamming distance: ORBMatcher::match(descriptors,
+    # ref_descriptors, matches, true) = cv::BFMatcher + filterMatches (orb_matcher.cpp:719-733) gives 776 on the
+    # oracle's descriptors, and filterMatches' rule max(2 * min, 30) (orb_matcher.cpp:905) is the customary one for
+    # Hamming distances.  This is an observation about the window, not the reference's test.
     p = _params(oracle, nfeatures=8000)
     d = []
     for img in test_images:
@@ -96,8 +131,41 @@ def test_filtered_match_window_under_hamming_distance(oracle, test_images):
         d.append(oracle.compute(p, img, k)[1])
     idx, dist = oracle.match_hamming(d[0], d[1])
     f = oracle.filter_matches(oracle.matches_from(idx, dist), len(d[0]))
-    assert 750 <= len(f) <= 800
     assert len(f) == 776
+
+
+def _pattern_ints(path):
+    import re
+    with open(path) as fh:
+        text = re.sub(r"/\*.*?\*/|//[^\n]*", "", fh.read(), flags=re.S)
+    return [int(t) for t in re.findall(r"-?\d+", text)]
+
+
+def test_sampling_pattern_table_is_intact():
+    """The rBRIEF sampling pattern (cv::ORB's bit_pattern_31_) exists twice, once for the oracle and once for the HIP
+    kernels; a wrong entry in both would pass every HIP-vs-oracle comparison.  Checked here without either of them:
+    the two files hold the same 1024 integers, their digest is the one recorded when the table was transcribed, and
+    the table has the structure of the published one - 256 tests of two distinct points, every coordinate inside the
+    31 x 31 patch by the margin the 5 x 5 smoothing windows of the rBRIEF learning left (-13 .. 12, so that a rotated
+    point stays within 15 * sqrt(2) < 19 pixels of the centre), no test listed twice, first test (8,-3)-(9,5)."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = _pattern_ints(os.path.join(root, "oracle", "bit_pattern_31.inc"))
+    b = _pattern_ints(os.path.join(root, "orb_slam_amd", "csrc", "bit_pattern_31.inc"))
+    assert a == b and len(a) == 1024
+    digest = hashlib.sha256(",".join(str(v) for v in a).encode()).hexdigest()
+    assert digest == "88df8ca875cc8db56799edd57bb914edad8acb2d48c202b7a464a575b55dbdb8"
+    t = np.array(a).reshape(256, 4)
+    assert t.min() == -13 and t.max() == 12
+    assert not np.any((t[:, 0] == t[:, 2]) & (t[:, 1] == t[:, 3]))
+    assert len({tuple(r) for r in t.tolist()}) == 256
+    assert t[0].tolist() == [8, -3, 9, 5] and t[255].tolist() == [-1, -6, 0, -11]
+    # the learning stage picked tests of high variance and low correlation: points spread over the whole patch,
+    # all four quadrants used by both end points
+    for col in (0, 2):
+        assert (t[:, col] < 0).sum() > 64 and (t[:, col] >= 0).sum() > 64
+        assert (t[:, col + 1] < 0).sum() > 64 and (t[:, col + 1] >= 0).sum() > 64
 
 
 def test_svd_null_vector_8x9(oracle):
