@@ -34,16 +34,20 @@ public:
         orbx_extractor_params p = {
             n_key_points_, scale_factor_, level_pyramid_, edge_threshold_, first_level_, wta_k_, patch_size_,
             score_threshold_};
-        orbx_extractor* h = nullptr;
-        orbx_compat::check(orbx_extractor_create(&p, max_width, max_height, 1, device, &h), "ORBExtractor");
-        handle_ = std::shared_ptr<orbx_extractor>(h, orbx_extractor_destroy);
+        handle_ = orbx_compat::PerThreadHandle<orbx_extractor>(
+            [p, max_width, max_height, device]() {
+                orbx_extractor* h = nullptr;
+                orbx_compat::check(orbx_extractor_create(&p, max_width, max_height, 1, device, &h), "ORBExtractor");
+                return h;
+            },
+            orbx_extractor_destroy);
 
         scale_factors_.resize(level_pyramid_);
         scale_sigma_sqrd_.resize(level_pyramid_);
         inv_scale_factors_.resize(level_pyramid_);
         inv_scale_sigma_sqrd_.resize(level_pyramid_);
         orbx_extractor_scale_tables(
-            h, scale_factors_.data(), inv_scale_factors_.data(), scale_sigma_sqrd_.data(),
+            handle_.get(), scale_factors_.data(), inv_scale_factors_.data(), scale_sigma_sqrd_.data(),
             inv_scale_sigma_sqrd_.data(), &log_scale_factor_);
     }
 
@@ -109,28 +113,28 @@ public:
     }
 
 private:
-    //! parameter source
     ros::NodeHandle nh_;
 
-    //! orb extractor parameters
-    int n_key_points_; // number of key points to extract
-    float log_scale_factor_; // log of scale factor
-    float scale_factor_; // feature scale factor
-    int level_pyramid_; // image pyramid level
-    int edge_threshold_ = {31}; // edge threshold
-    int first_level_ = {0}; // first level
-    int wta_k_ = {2}; // wta_k
-    int patch_size_ = {31}; // patch size
-    int score_threshold_; // score threshold
+    // values of the orb_slam/orb_extractor/* keys
+    int n_key_points_;
+    float scale_factor_;
+    int level_pyramid_;
+    int edge_threshold_ = 31;
+    int first_level_ = 0;
+    int wta_k_ = 2;
+    int patch_size_ = 31;
+    int score_threshold_;
 
+    // per-level tables handed out by the getters; filled once from the device-side extractor
+    float log_scale_factor_;
     std::vector<float> scale_factors_;
     std::vector<float> inv_scale_factors_;
     std::vector<float> scale_sigma_sqrd_;
     std::vector<float> inv_scale_sigma_sqrd_;
 
-    //! device-side extractor (replaces the two cv::ORB objects)
-    std::shared_ptr<orbx_extractor> handle_;
-    std::string name_tag_ = {"ORBExtractor"};
+    // one orbx_extractor per calling thread stands where the reference holds its two cv::ORB objects; the object
+    // itself is shared through static members (frame.h:520), so calls may arrive from more than one thread
+    orbx_compat::PerThreadHandle<orbx_extractor> handle_;
 };
 
 using ORBExtractorPtr = std::shared_ptr<ORBExtractor>;

@@ -46,9 +46,13 @@ public:
         nh_.getParam("orb_slam/cv_orb_matcher/type", type);
         if (type != "BruteForce-Hamming")
             throw std::runtime_error("ORBMatcher: only cv_orb_matcher/type BruteForce-Hamming is implemented");
-        orbx_matcher* h = nullptr;
-        orbx_compat::check(orbx_matcher_create(device, &h), "ORBMatcher");
-        handle_ = std::shared_ptr<orbx_matcher>(h, orbx_matcher_destroy);
+        handle_ = orbx_compat::PerThreadHandle<orbx_matcher>(
+            [device]() {
+                orbx_matcher* h = nullptr;
+                orbx_compat::check(orbx_matcher_create(device, &h), "ORBMatcher");
+                return h;
+            },
+            orbx_matcher_destroy);
     }
 
     ~ORBMatcher() {}
@@ -422,7 +426,9 @@ private:
     ros::NodeHandle nh_;
     std::string method_;
     double max_matching_pixel_dist_ = 0.0;
-    std::shared_ptr<orbx_matcher> handle_;
+    //! one device-side matcher per calling thread: the reference shares this object between the tracker and the
+    //! local-mapper thread (frame.h:521-522, map_point.h:240-241)
+    orbx_compat::PerThreadHandle<orbx_matcher> handle_;
 };
 
 using ORBMatcherPtr = std::shared_ptr<ORBMatcher>;

@@ -1,19 +1,23 @@
 /*
- * Drop-in counterpart of the reference's Initializer for the F/H RANSAC part (include/orb_slam/initializer.h:29-79,
- * src/Initializer.cpp:254-585): same member names for the pieces on the hot path.  The frame/camera constructor
- * arguments of the reference are not needed by this part and are left to the caller; setPoints / setRefPoints /
- * findFundamentalAndHomography / the getters are the reference's own test seam.  One additive seam:
- * setRansacSets() injects the 8-index sets; without it they are drawn as in the reference (std::shuffle seeded
- * from std::random_device, cumulative over iterations, Initializer.cpp:261-277).
+ * Drop-in counterpart of the reference's Initializer (include/orb_slam/initializer.h:26-223, src/Initializer.cpp):
+ * the same constructor (ref_frame, camera, sigma = 1.0, iterations = 200), tryToInitialize(frame, ...), the getters,
+ * setPoints / setRefPoints / findFundamentalAndHomography (the reference's own test seam), findRtWithHomography,
+ * findRtWithFundamental and triangulatePoints, so src/mono_tracker.cpp:81-87,127-134 and
+ * src/tests/initializer_tests.cpp:118-124 compile against it unchanged.  The two-view RANSAC and the pose recovery
+ * run on the device through orbx_ransac_* (include/orbx.h).
  *
- * Pose recovery (Initializer.cpp:30-252): tryToInitialize, findRtWithFundamental and triangulatePoints keep the
- * reference's signatures, minus the frame argument (the frame only supplies the matched points, :44-53, which
- * arrive here through setPoints / setRefPoints); the camera enters as its 3x3 intrinsic matrix (CV_32F, what
- * camera_->intrinsicMatrix() returns) through setIntrinsicMatrix().
+ * The reference's header only forward-declares Frame and Camera and its .cpp sees the full types; this header has
+ * no .cpp, so the constructor and tryToInitialize are templates over the pointer types: they are instantiated at
+ * the call site, where the caller has the full types, and they use exactly the accessors the reference uses
+ * (Frame::nMatches / matches / featuresUndist, Initializer.cpp:44-53; Camera::intrinsicMatrix, :124,174,218).
+ *
+ * One additive seam: setRansacSets() injects the 8-index sets; without it they are drawn as in the reference
+ * (std::shuffle seeded from std::random_device, cumulative over iterations, Initializer.cpp:261-277).
  */
 #pragma once
 
 #include <algorithm>
+#include <functional>
 #include <random>
 #include <vector>
 
@@ -21,26 +25,52 @@
 
 namespace orb_slam {
 
+namespace geometry {
+    template <typename T>
+    class Camera;
+    template <typename T>
+    using CameraPtr = std::shared_ptr<Camera<T>>;
+}
+
+class Frame;
+using FramePtr = std::shared_ptr<Frame>;
+
 class Initializer {
 public:
-    Initializer(double sigma = 1.0, int iterations = 200, int device = 0) :
+    /**
+     * Initializer::Initializer (Initializer.cpp:13-24).  ref_frame: the first frame to initialise against (may be
+     * null: the reference only warns); camera: provides intrinsicMatrix().  `device` (additive, defaulted) picks the GPU.
+     */
+    template <typename FrameT, typename CameraT>
+    Initializer(
+        const std::shared_ptr<FrameT>& ref_frame,
+        const std::shared_ptr<CameraT>& camera,
+        double sigma = 1.0,
+        int iterations = 200,
+        int device = 0) :
         sigma_(sigma), iterations_(iterations)
     {
         sigma_squared_ = sigma * sigma;
+        has_ref_frame_ = static_cast<bool>(ref_frame);
+        if (ref_frame)
+            ref_features_ = [ref_frame]() -> const std::vector<cv::KeyPoint>& { return ref_frame->featuresUndist(); };
+        if (camera)
+            intrinsic_of_camera_ = [camera]() { return toFloat33(camera->intrinsicMatrix()); };
         orbx_ransac* h = nullptr;
         orbx_compat::check(orbx_ransac_create(device, &h), "Initializer");
         handle_ = std::shared_ptr<orbx_ransac>(h, orbx_ransac_destroy);
     }
 
-    void setRefPoints(const std::vector<cv::Point2f>& ref_points) { ref_points_ = ref_points; }
-    void setPoints(const std::vector<cv::Point2f>& points) { points_ = points; }
-    void setRansacSets(const std::vector<std::vector<size_t>>& sets) { ransac_sets_ = sets; injected_ = true; }
-    void setIntrinsicMatrix(const cv::Mat& K) { intrinsic_ = K.clone(); }
+    ~Initializer() {}
 
     /**
-     * Initializer::tryToInitialize (Initializer.cpp:30-110) on the points given by setPoints / setRefPoints.
+     * Initializer::tryToInitialize (Initializer.cpp:30-110): gathers the matched undistorted points of `frame` and
+     * of the reference frame (:44-53), finds F and H, picks the model by the score ratio (:59-92), recovers R, t and
+     * triangulates.
      */
+    template <typename FrameT>
     bool tryToInitialize(
+        const std::shared_ptr<FrameT>& frame,
         cv::Mat& best_rot_mat,
         cv::Mat& best_trans_mat,
         std::vector<cv::Point2d>& inlier_points,
@@ -48,8 +78,23 @@ public:
         std::vector<cv::Point3d>& inlier_points_3d,
         std::vector<size_t>& inliers_idxs)
     {
-        const int n = (int)points_.size();
+        if (!has_ref_frame_) {
+            // the reference warns and then dereferences the null frame; here the call fails instead
+            return false;
+        }
+        const int n = frame->nMatches();
+        const auto& matches = frame->matches();
+        const auto& undist_key_points = frame->featuresUndist();
+        const auto& undist_ref_key_points = ref_features_();
+        ref_points_.resize(n);
+        points_.resize(n);
+        for (int i = 0; i < n; ++i) {
+            ref_points_[i] = undist_ref_key_points[matches[i].trainIdx].pt;
+            points_[i] = undist_key_points[matches[i].queryIdx].pt;
+        }
+
         findFundamentalAndHomography();
+
         float r_score = h_score_ / (h_score_ + f_score_);
         const bool use_h = r_score > 0.40;
         const std::vector<bool>& inl = use_h ? inliers_h_ : inliers_f_;
@@ -68,6 +113,11 @@ public:
         }
         return triangulatePoints(inlier_points, inlier_ref_points, best_rot_mat, best_trans_mat, inlier_points_3d);
     }
+
+    void setRefPoints(const std::vector<cv::Point2f>& ref_points) { ref_points_ = ref_points; }
+    void setPoints(const std::vector<cv::Point2f>& points) { points_ = points; }
+    /** Additive: the 8-index sets of every iteration (ransac_sets_ of the reference, private there). */
+    void setRansacSets(const std::vector<std::vector<size_t>>& sets) { ransac_sets_ = sets; injected_ = true; }
 
     /**
      * Initializer::findRtWithHomography (Initializer.cpp:112-163).  The reference hands std::vector<cv::Point2d>
@@ -88,6 +138,7 @@ public:
         cv::Mat& R,
         cv::Mat& t)
     {
+        const cv::Mat intrinsic_ = intrinsic();
         if (fundamental_mat_.empty() || intrinsic_.empty()) return false; // cv::Exception path of the reference
         const int32_t start[2] = {0, (int32_t)inlier_points.size()};
         double r9[9], t3[3];
@@ -112,6 +163,7 @@ public:
         const cv::Mat& t,
         std::vector<cv::Point3d>& inlier_points_3d)
     {
+        const cv::Mat intrinsic_ = intrinsic();
         if (R.empty() || t.empty() || intrinsic_.empty()) return false; // cv::hconcat / gemm would throw
         const int n = (int)inlier_points.size();
         const int32_t start[2] = {0, n};
@@ -126,10 +178,10 @@ public:
         return true;
     }
 
-    const cv::Mat& getFundamentalMat() const { return fundamental_mat_; }
-    const cv::Mat& getHomographyMat() const { return homography_mat_; }
-    const std::vector<bool>& getInliersF() const { return inliers_f_; }
-    const std::vector<bool>& getInliersH() const { return inliers_h_; }
+    cv::Mat getFundamentalMat() { return fundamental_mat_; }
+    cv::Mat getHomographyMat() { return homography_mat_; }
+    std::vector<bool> getInliersF() { return inliers_f_; }
+    std::vector<bool> getInliersH() { return inliers_h_; }
     double fScore() const { return f_score_; }
     double hScore() const { return h_score_; }
 
@@ -165,6 +217,16 @@ public:
     }
 
 private:
+    //! Camera::intrinsicMatrix() (a cv::Mat_<float> in the reference) as a continuous 3x3 CV_32F matrix
+    template <typename MatT>
+    static cv::Mat toFloat33(const MatT& K) {
+        cv::Mat out(3, 3, CV_32F);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) out.at<float>(r, c) = K.template at<float>(r, c);
+        return out;
+    }
+    cv::Mat intrinsic() const { return intrinsic_of_camera_ ? intrinsic_of_camera_() : cv::Mat(); }
+
     static cv::Mat toMat(const float* m) {
         cv::Mat out(3, 3, CV_32F);
         std::memcpy(out.data, m, 9 * sizeof(float));
@@ -176,10 +238,15 @@ private:
     bool injected_ = false;
     std::vector<cv::Point2f> points_, ref_points_;
     std::vector<std::vector<size_t>> ransac_sets_;
-    cv::Mat fundamental_mat_, homography_mat_, intrinsic_;
+    cv::Mat fundamental_mat_, homography_mat_;
+    bool has_ref_frame_ = false;
+    std::function<const std::vector<cv::KeyPoint>&()> ref_features_;  // ref_frame_->featuresUndist()
+    std::function<cv::Mat()> intrinsic_of_camera_;                    // camera_->intrinsicMatrix()
     std::vector<bool> inliers_f_, inliers_h_;
     double f_score_ = 0.0, h_score_ = 0.0;
     std::shared_ptr<orbx_ransac> handle_;
 };
+
+using InitializerPtr = std::unique_ptr<Initializer>;
 
 } // namespace orb_slam

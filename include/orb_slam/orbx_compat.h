@@ -9,11 +9,14 @@
 #include <cstdint>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "orbx.h"
@@ -155,4 +158,44 @@ inline void check(orbx_status s, const char* where) {
     if (s != ORBX_OK)
         throw std::runtime_error(std::string(where) + ": " + orbx_status_string(s) + " " + orbx_last_error());
 }
+
+/*
+ * One C-ABI handle per calling thread behind a facade object.  The reference keeps ONE ORBExtractor and ONE
+ * ORBMatcher in static members (include/orb_slam/frame.h:520-522, map_point.h:240-241) and calls them from the
+ * tracker thread and the local-mapper thread at the same time (src/tracker.cpp:310, src/local_mapping/
+ * local_mapper.cpp:277,462,480); an orbx handle owns one stream and one set of device buffers and is not
+ * re-entrant.  get() hands every thread its own handle (created on the thread's first call), so concurrent calls
+ * through one facade object never share device state and never wait for each other.  The state lives behind a
+ * shared_ptr: copies of a facade object share the pool, as copies of the reference's classes share their cv::Ptr.
+ */
+template <typename H>
+class PerThreadHandle {
+public:
+    PerThreadHandle() {}
+    PerThreadHandle(std::function<H*()> make, void (*destroy)(H*)) : state_(std::make_shared<State>()) {
+        state_->make = std::move(make);
+        state_->destroy = destroy;
+        get();  // the constructing thread's handle: a missing GPU shows at construction, as a throw
+    }
+    H* get() const {
+        const std::thread::id id = std::this_thread::get_id();
+        std::lock_guard<std::mutex> lock(state_->mutex);
+        auto it = state_->handles.find(id);
+        if (it == state_->handles.end())
+            it = state_->handles.emplace(id, std::shared_ptr<H>(state_->make(), state_->destroy)).first;
+        return it->second.get();
+    }
+    size_t size() const {
+        std::lock_guard<std::mutex> lock(state_->mutex);
+        return state_->handles.size();
+    }
+private:
+    struct State {
+        std::mutex mutex;
+        std::function<H*()> make;
+        void (*destroy)(H*) = nullptr;
+        std::map<std::thread::id, std::shared_ptr<H>> handles;
+    };
+    std::shared_ptr<State> state_;
+};
 }  // namespace orbx_compat

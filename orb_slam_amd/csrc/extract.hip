@@ -305,6 +305,19 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     return ORBX_OK;
 }
 
+// A batch call forks the blur onto the side stream (run_detect_stage with fork_blur) and run_describe_stage joins it.
+// Every other way out of that window - a capacity error, a failed allocation, the next call arriving first - must
+// join it as well, or the next describe stage would wait on a stale event and skip its own blur.
+void join_blur_fork(orbx_extractor* h) {
+    if (!h->blur_forked) return;
+    (void)hipStreamWaitEvent(h->stream, h->ev_blur, 0);
+    h->blur_forked = false;
+}
+struct BlurForkGuard {
+    orbx_extractor* h;
+    ~BlurForkGuard() { join_blur_fork(h); }
+};
+
 // Launch shape of k_gray_level0: x covers the larger of its two regions (interior 16-pixel groups, edge pixels).
 dim3 gray_grid(const Geom& g, int w, int hgt, int frames) {
     const int border = g.border, rx = g.L[0].x;
@@ -349,6 +362,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     size_t A = h->atlas_bytes;
     StageTimer& T = h->timer;
     T.clear();
+    join_blur_fork(h);
     const int border = g.border;
     T.begin(ST_GRAY, s);
     {
@@ -408,6 +422,7 @@ orbx_status run_pyramid(orbx_extractor* h, const uint8_t* d_images, int frames, 
     hipStream_t s = h->stream;
     size_t A = h->atlas_bytes;
     const int border = g.border;
+    join_blur_fork(h);
     h->timer.begin(ST_GRAY, s);
     dim3 grid = gray_grid(g, w, hgt, frames);
     hipLaunchKernelGGL(k_gray_level0, grid, dim3(256), 0, s, d_images, frame_stride, w, hgt, stride, ch, h->d_atlas.p,
@@ -779,6 +794,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
     ORBX_TRY(ensure_buffers(h, n_frames));
     h->last_frames = n_frames;
+    BlurForkGuard fork_guard{h};  // whichever way this call ends, the side stream is joined
     ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, true));
 
     // Device-resident path: selection, undistortion, bucket grid and border filter run in one kernel per frame

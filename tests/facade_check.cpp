@@ -7,6 +7,7 @@
 
 #include <map>
 #include <memory>
+#include <thread>
 
 using namespace orb_slam;
 using namespace orb_slam::geometry;
@@ -41,6 +42,13 @@ struct MockMapPoint {
     void replace(const std::shared_ptr<MockMapPoint>&) { bad = true; }
 };
 struct MockCamera {
+    cv::Mat K;
+    MockCamera() {
+        K.create(3, 3, CV_32F);
+        const float kv[9] = {525.f, 0.f, 319.5f, 0.f, 525.f, 239.5f, 0.f, 0.f, 1.f};
+        std::memcpy(K.data, kv, sizeof(kv));
+    }
+    const cv::Mat& intrinsicMatrix() const { return K; }
     float minX() const { return 0.f; }
     float minY() const { return 0.f; }
     float maxX() const { return 640.f; }
@@ -54,6 +62,9 @@ struct MockFrame {
     std::map<unsigned, std::vector<unsigned>> bow;
     std::shared_ptr<MockCamera> cam = std::make_shared<MockCamera>();
     std::shared_ptr<ORBExtractor> extractor;
+    std::vector<cv::DMatch> matches_;
+    const std::vector<cv::DMatch>& matches() const { return matches_; }
+    const int nMatches() const { return (int)matches_.size(); }
     const std::vector<cv::KeyPoint>& featuresUndist() const { return kps; }
     const cv::Mat& descriptorsUndist() const { return desc; }
     const std::map<unsigned, std::vector<unsigned>>& bowFeatures() const { return bow; }
@@ -142,40 +153,98 @@ int main(int argc, char** argv) {
         const int fused_again = mt.fuse(ka, pts, 3.0f);
         std::printf("fused=%d attached=%zu fused_again=%d\n", fused, attached, fused_again);
     }
-    Initializer init(1.0, 50);
-    std::vector<cv::Point2f> p, r;
-    for (auto& mm : m) { p.push_back(k1[mm.queryIdx].pt); r.push_back(k2[mm.trainIdx].pt); }
-    if (p.size() >= 8) {
-        init.setPoints(p); init.setRefPoints(r);
-        init.findFundamentalAndHomography();
-        std::printf("H empty=%d score_h=%.3f\n", (int)init.getHomographyMat().empty(), init.hScore());
-        // pose recovery from the fundamental matrix of a synthetic rigid scene, then triangulation
-        cv::Mat K(3, 3, CV_32F);
-        const float kv[9] = {525.f, 0.f, 319.5f, 0.f, 525.f, 239.5f, 0.f, 0.f, 1.f};
-        std::memcpy(K.data, kv, sizeof(kv));
-        std::vector<cv::Point2f> sp, sr;
+    {
+        // the reference shares one ORBMatcher / ORBExtractor between the tracker thread and the local-mapper thread
+        // (frame.h:520-522): the same calls from two threads at once must give what they give alone
+        std::vector<cv::DMatch> ma[2];
+        std::vector<cv::KeyPoint> ka[2];
+        cv::Mat da[2];
+        bool same = true;
+        for (int round = 0; round < 3 && same; round++) {
+            std::thread th[2];
+            for (int t = 0; t < 2; t++)
+                th[t] = std::thread([&, t]() {
+                    for (int rep = 0; rep < 4; rep++) {
+                        ma[t].clear();
+                        if (t == 0) mt.match(d1, d2, ma[t], true);
+                        else mt.match(k1, k2, d1, d2, ma[t], false);
+                        ex.detect(img, ka[t]);
+                        ex.compute(img, ka[t], da[t]);
+                    }
+                });
+            for (auto& x : th) x.join();
+            std::vector<cv::DMatch> mr;
+            mt.match(k1, k2, d1, d2, mr, false);
+            same = ma[0].size() == m.size() && ma[1].size() == mr.size();
+            for (size_t i = 0; same && i < m.size(); i++) same = ma[0][i].trainIdx == m[i].trainIdx && ma[0][i].queryIdx == m[i].queryIdx;
+            for (size_t i = 0; same && i < mr.size(); i++) same = ma[1][i].trainIdx == mr[i].trainIdx && ma[1][i].distance == mr[i].distance;
+            for (int t = 0; t < 2 && same; t++)
+                same = ka[t].size() == k1.size() && da[t].rows == d1.rows &&
+                       std::memcmp(da[t].data, d1.data, (size_t)d1.rows * 32) == 0 &&
+                       std::memcmp(ka[t].data(), k1.data(), k1.size() * sizeof(cv::KeyPoint)) == 0;
+        }
+        std::printf("two_threads_same=%d\n", (int)same);
+    }
+    // Initializer through the reference's own constructor and tryToInitialize (mono_tracker.cpp:81-87,127-134)
+    auto ref_frame = std::make_shared<MockFrame>(), cur_frame = std::make_shared<MockFrame>();
+    auto camera = std::make_shared<MockCamera>();
+    ref_frame->kps = k2;
+    cur_frame->kps = k1;
+    cur_frame->matches_ = m;
+    InitializerPtr init = InitializerPtr(new Initializer(ref_frame, camera, 1.0, 50));
+    if (m.size() >= 8) {
+        cv::Mat R0, t0;
+        std::vector<cv::Point2d> ip0, ir0;
+        std::vector<cv::Point3d> x0;
+        std::vector<size_t> idx0;
+        // identical views: every hypothesis is degenerate in the same way for F; the call must come back either way
+        const bool ok0 = init->tryToInitialize(cur_frame, R0, t0, ip0, ir0, x0, idx0);
+        std::printf("H empty=%d init_identical=%d\n", (int)init->getHomographyMat().empty(), (int)ok0);
+        // a synthetic rigid scene: matches, F/H RANSAC with injected sets, pose recovery, triangulation
+        auto fr = std::make_shared<MockFrame>(), fc = std::make_shared<MockFrame>();
         unsigned q = 7;
         auto rnd = [&]() { q = q * 1664525u + 1013904223u; return (q >> 8) / 16777216.0; };
         for (int i = 0; i < 300; i++) {
             const double X = rnd() * 4 - 2, Y = rnd() * 3 - 1.5, Z = 2 + rnd() * 4, a = 0.05;
             const double x2 = std::cos(a) * X + std::sin(a) * Z + 0.3, y2 = Y + 0.02, z2 = -std::sin(a) * X + std::cos(a) * Z + 0.05;
-            sr.emplace_back((float)(525 * X / Z + 319.5), (float)(525 * Y / Z + 239.5));
-            sp.emplace_back((float)(525 * x2 / z2 + 319.5), (float)(525 * y2 / z2 + 239.5));
+            cv::KeyPoint kr, kc;
+            kr.pt = cv::Point2f((float)(525 * X / Z + 319.5), (float)(525 * Y / Z + 239.5));
+            kc.pt = cv::Point2f((float)(525 * x2 / z2 + 319.5), (float)(525 * y2 / z2 + 239.5));
+            // the match list pairs query 299 - i of the current frame with train i of the reference frame
+            fr->kps.push_back(kr);
+            fc->kps.insert(fc->kps.begin(), kc);
+            fc->matches_.push_back(cv::DMatch(299 - i, i, 0.f));
         }
-        Initializer init2(1.0, 200);
-        init2.setPoints(sp); init2.setRefPoints(sr); init2.setIntrinsicMatrix(K);
-        init2.findFundamentalAndHomography();
-        std::vector<cv::Point2d> ip, ir;
-        for (size_t i = 0; i < sp.size(); i++)
-            if (init2.getInliersF()[i]) { ip.emplace_back(sp[i].x, sp[i].y); ir.emplace_back(sr[i].x, sr[i].y); }
+        Initializer init2(fr, camera, 1.0, 200);
+        std::vector<std::vector<size_t>> sets(200, std::vector<size_t>(8));
+        for (auto& st : sets)
+            for (int j = 0; j < 8; j++) {
+                bool again = true;
+                while (again) {
+                    st[j] = (size_t)(rnd() * 300) % 300;
+                    again = false;
+                    for (int k = 0; k < j; k++) again = again || st[k] == st[j];
+                }
+            }
+        init2.setRansacSets(sets);
         cv::Mat Rm, tm;
+        std::vector<cv::Point2d> ip, ir;
         std::vector<cv::Point3d> xyz;
-        const bool ok_rt = init2.findRtWithFundamental(ip, ir, Rm, tm);
-        const bool ok_tri = ok_rt && init2.triangulatePoints(ip, ir, Rm, tm, xyz);
+        std::vector<size_t> idx;
+        const bool ok = init2.tryToInitialize(fc, Rm, tm, ip, ir, xyz, idx);
         int in_front = 0;
         for (auto& P3 : xyz) in_front += P3.z > 0;
-        std::printf("pose ok=%d tri=%d inliers=%zu in_front=%d r00=%.4f tx=%.3f\n", (int)ok_rt, (int)ok_tri, ip.size(),
-                    in_front, ok_rt ? Rm.at<double>(0, 0) : 0.0, ok_rt ? tm.at<double>(0, 0) : 0.0);
+        std::printf("pose ok=%d tri=%d inliers=%zu in_front=%d r00=%.4f tx=%.3f\n", (int)ok, (int)(xyz.size() == ip.size()),
+                    ip.size(), in_front, ok ? Rm.at<double>(0, 0) : 0.0, ok ? tm.at<double>(0, 0) : 0.0);
+        // the test seam of the reference: points set directly, then the public solver and the getters
+        std::vector<cv::Point2f> sp, sr;
+        for (auto& mm : fc->matches_) { sp.push_back(fc->kps[mm.queryIdx].pt); sr.push_back(fr->kps[mm.trainIdx].pt); }
+        Initializer init3(fr, camera, 1.0, 200);
+        init3.setRansacSets(sets);
+        init3.setPoints(sp); init3.setRefPoints(sr);
+        init3.findFundamentalAndHomography();
+        cv::Mat F2 = init2.getFundamentalMat(), F3 = init3.getFundamentalMat();
+        std::printf("seam_same_F=%d\n", (int)(!F2.empty() && !F3.empty() && std::memcmp(F2.data, F3.data, 36) == 0));
     }
     return 0;
 }

@@ -162,6 +162,28 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     ex.close()
 
 
+def test_compute_after_a_failed_batch(oracle, test_images):
+    """A batch forks its blur onto a side stream; a batch that fails between the fork and the describe stage (host
+    selection, more keypoints than the caller's capacity) must leave the handle clean: the next compute on the same
+    handle blurs its own pyramid and matches the oracle bit for bit."""
+    import torch
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=2)
+    p = oracle.orb_params(nfeatures=1000)
+    dev = torch.from_numpy(np.stack([test_images[0], synth_image(71, 640, 480, 3)])).cuda()
+    torch.cuda.synchronize()
+    other = test_images[1]
+    ok = oracle.detect(p, other)
+    want_k, want_d = oracle.compute(p, other, ok)
+    for device_select in (False, True):
+        ex.set_device_select(device_select)
+        with pytest.raises(orbx.OrbxError) as e:
+            ex.extract_batch(dev.data_ptr(), 2, 640 * 480 * 3, 640, 480, 640 * 3, 3, 400)
+        assert e.value.status == orbx.CAPACITY
+        k, d = ex.compute(other, ok.astype(orbx.KP_DTYPE))
+        assert np.array_equal(k, want_k.astype(orbx.KP_DTYPE)) and np.array_equal(d, want_d), device_select
+    ex.close()
+
+
 def test_selection_launch_tiers(oracle, test_images):
     """The selection kernel is launched with a small LDS footprint first and full-size for the frames left over; how
     many candidates the small launch holds depends on the keypoint capacity.  Capacities on both sides of every
