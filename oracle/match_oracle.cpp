@@ -152,8 +152,11 @@ bool box_around(const orc_grid_params* g, float px, float py, float r, int& left
 
 /* frame.cpp:151-183 (4-argument overload: compares keypoint coordinates with the CELL index) and
    frame.cpp:185-218 (5-argument overload). min-only mode selects the former. */
+/* A grid built before cv::ORB::compute dropped border keypoints (mono_frame.cpp:97-103) names slots past the end of
+   the shortened vector; the reference reads beyond its vector there.  Defined here as: such an entry names no
+   feature (n = number of keypoints). */
 bool features_around(const orc_grid_params* g, const int32_t* cell_start, const int32_t* cell_items,
-                     const orc_keypoint* kps, float px, float py, float radius, int min_level, int max_level,
+                     const orc_keypoint* kps, int n, float px, float py, float radius, int min_level, int max_level,
                      bool min_only, std::vector<int>& out) {
     int left, right, up, down;
     if (!box_around(g, px, py, radius, left, right, up, down)) return false;
@@ -161,6 +164,7 @@ bool features_around(const orc_grid_params* g, const int32_t* cell_start, const 
         for (int y = up; y <= down; ++y) {
             int c = x * g->grid_rows + y;
             for (int i = cell_start[c]; i < cell_start[c + 1]; i++) {
+                if (cell_items[i] >= n) continue;
                 const orc_keypoint& k = kps[cell_items[i]];
                 if (min_only) {
                     if (k.octave < min_level) continue;
@@ -210,9 +214,9 @@ int orc_match_projection_frame(const orc_grid_params* g, const int32_t* cell_sta
         float radius_scaled = radius * scale_factors[level];
         std::vector<int> close;
         bool ok;
-        if (level_mode == 1) ok = features_around(g, cell_start, cell_items, kps, px, py, radius_scaled, level, 0, true, close);
-        else if (level_mode == 2) ok = features_around(g, cell_start, cell_items, kps, px, py, radius_scaled, 0, level, false, close);
-        else ok = features_around(g, cell_start, cell_items, kps, px, py, radius_scaled, level - 1, level + 1, false, close);
+        if (level_mode == 1) ok = features_around(g, cell_start, cell_items, kps, n, px, py, radius_scaled, level, 0, true, close);
+        else if (level_mode == 2) ok = features_around(g, cell_start, cell_items, kps, n, px, py, radius_scaled, 0, level, false, close);
+        else ok = features_around(g, cell_start, cell_items, kps, n, px, py, radius_scaled, level - 1, level + 1, false, close);
         if (!ok) continue;
         int min_dist = 256, matched_id = -1;
         for (int idx : close) {
@@ -258,7 +262,7 @@ int orc_match_projection_points(const orc_grid_params* g, const int32_t* cell_st
         float by_cos = view_cos[ref_idx] > 0.998 ? 2.5f : 4.0f; /* orb_matcher.h:50-55 */
         float radius_scaled = radius * by_cos * scale_factors[level];
         std::vector<int> close;
-        if (!features_around(g, cell_start, cell_items, kps, proj_xy[2 * ref_idx], proj_xy[2 * ref_idx + 1],
+        if (!features_around(g, cell_start, cell_items, kps, n, proj_xy[2 * ref_idx], proj_xy[2 * ref_idx + 1],
                              radius_scaled, level - 1, level, false, close))
             continue;
         int min_dist = 256, id1 = -1, min2 = 256, id2 = -1;
@@ -423,6 +427,7 @@ void orc_fuse_search(const orc_grid_params* g, const int32_t* cell_start, const 
                      const float* proj_xy, const int32_t* pred_level, const uint8_t* pt_desc,
                      const float* scale_factors, const float* inv_scale_sigmas, float radius_multiplier,
                      int32_t* best_idx, int32_t* best_dist) {
+    const int n = 0x7fffffff; /* the grid of a key frame is built from the very keypoints passed here */
     for (int p = 0; p < n_pts; ++p) {
         best_idx[p] = -1;
         best_dist[p] = 256;
@@ -431,7 +436,7 @@ void orc_fuse_search(const orc_grid_params* g, const int32_t* cell_start, const 
         const float px = proj_xy[2 * p], py = proj_xy[2 * p + 1];
         const float radius_scaled = radius_multiplier * scale_factors[level];
         std::vector<int> close;
-        if (!features_around(g, cell_start, cell_items, kps, px, py, radius_scaled, level - 1, level, false, close))
+        if (!features_around(g, cell_start, cell_items, kps, n, px, py, radius_scaled, level - 1, level, false, close))
             continue;
         int min_feature_dist = 256, matched_id = -1;
         for (int idx : close) {

@@ -284,7 +284,7 @@ orbx_status ensure_buffers(orbx_extractor* h, int frames) {
     ORBX_TRY(h->d_blur.ensure(A * frames + 64));
     ORBX_TRY(h->d_mask.ensure((size_t)g.total_words * frames));
     // candidate capacity: a strict 3x3 maximum can occur at most once per 2x2 pixels; a quarter of that bound is
-    // ample for natural images and overflow is reported, not truncated.
+    // ample for natural images, and a frame that exceeds it makes the list grow (regrow_candidates).
     size_t px = 0;
     for (int l = 0; l < g.nlevels; l++) px += (size_t)g.L[l].w * g.L[l].h;
     int cap = (int)std::min<size_t>(std::max<size_t>(px / 16, 4096), 1u << 20);
@@ -354,6 +354,47 @@ void launch_resize(orbx_extractor* h, int l, int frames, hipStream_t s) {
     }
 }
 
+// Ordered emission of the corners the FAST kernel marked, then Harris response and orientation of the candidates.
+void run_emit_and_harris(orbx_extractor* h, int frames) {
+    const Geom& g = h->geom;
+    hipStream_t s = h->stream;
+    size_t A = h->atlas_bytes;
+    StageTimer& T = h->timer;
+    T.begin(ST_EMIT, s);
+    {
+        const int chunks = h->emit_chunks, per = h->emit_per;
+        hipLaunchKernelGGL(k_emit_write, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, chunks,
+                           per, h->d_chunk_counts_p, h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_hist_p);
+        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(256), 0, s, g, chunks, h->d_chunk_counts_p,
+                           h->d_level_counts_p, h->d_hist_p, h->d_thresholds.p, h->d_totals.p);
+    }
+    T.end(ST_EMIT, s);
+    T.begin(ST_HARRIS, s);
+    {
+        const int chunks = frames >= 64 ? 32 : 256;
+        hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
+                           h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq,
+                           chunks, frames);
+    }
+    T.end(ST_HARRIS, s);
+}
+
+// A frame with more corners than the candidate list holds (cv::ORB has no such limit): the list is enlarged to the
+// largest per-frame total and emission + Harris/angle run again on the masks the FAST kernel left.  The per-run
+// corner counts come from the FAST kernel and stay; the per-level counts and histograms are accumulated by the
+// emission and start again from zero.
+orbx_status regrow_candidates(orbx_extractor* h, int frames, int needed) {
+    h->cand_cap = (needed + 1023) & ~1023;
+    ORBX_TRY(h->d_cand.ensure((size_t)h->cand_cap * frames));
+    ORBX_TRY(h->d_packed.ensure((size_t)h->cand_cap * frames));
+    hipStream_t s = h->stream;
+    ORBX_HIP(hipMemsetAsync(h->d_level_counts_p, 0, sizeof(int) * (size_t)frames * kMaxLevels, s));
+    ORBX_HIP(hipMemsetAsync(h->d_hist_p, 0, sizeof(int) * (size_t)frames * kMaxLevels * 256, s));
+    run_emit_and_harris(h, frames);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
 // Pyramid + FAST + NMS + ordered emission + Harris/angle for `frames` device-resident images.
 orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int frames, size_t frame_stride, int w,
                              int hgt, int stride, int ch, bool fork_blur = false) {
@@ -393,23 +434,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
         ORBX_HIP(hipEventRecord(h->ev_blur, h->side_stream));
         h->blur_forked = true;
     }
-    T.begin(ST_EMIT, s);
-    {
-        const int chunks = h->emit_chunks, per = h->emit_per;
-        hipLaunchKernelGGL(k_emit_write, dim3(chunks, frames), dim3(256), 0, s, h->d_mask.p, h->d_score.p, A, g, chunks,
-                           per, h->d_chunk_counts_p, h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_hist_p);
-        hipLaunchKernelGGL(k_emit_finish, dim3(frames), dim3(256), 0, s, g, chunks, h->d_chunk_counts_p,
-                           h->d_level_counts_p, h->d_hist_p, h->d_thresholds.p, h->d_totals.p);
-    }
-    T.end(ST_EMIT, s);
-    T.begin(ST_HARRIS, s);
-    {
-        const int chunks = frames >= 64 ? 32 : 256;
-        hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
-                           h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq,
-                           chunks, frames);
-    }
-    T.end(ST_HARRIS, s);
+    run_emit_and_harris(h, frames);
     ORBX_HIP(hipGetLastError());
     h->pyramid_valid = true;
     return ORBX_OK;
@@ -472,7 +497,8 @@ void collect_timings(orbx_extractor* h) {
 
 // Downloads the candidates of all frames and runs the host part of cv::ORB::detect per frame.
 // out[f] receives the final keypoints of frame f (level-0 coordinates).
-orbx_status select_keypoints(orbx_extractor* h, int frames, std::vector<std::vector<orbx_keypoint>>& out) {
+orbx_status select_keypoints(orbx_extractor* h, int frames, std::vector<std::vector<orbx_keypoint>>& out,
+                             bool regrown = false) {
     const Geom& g = h->geom;
     hipStream_t s = h->stream;
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(64), 0, s, h->d_totals.p, frames, h->cand_cap, h->d_offsets.p);
@@ -486,8 +512,13 @@ orbx_status select_keypoints(orbx_extractor* h, int frames, std::vector<std::vec
     ORBX_HIP(hipMemcpyAsync(h_offsets, h->d_offsets.p, sizeof(int) * (frames + 1), hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipMemcpyAsync(h_counts, h->d_level_counts_p, sizeof(int) * kMaxLevels * frames, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipStreamSynchronize(s));
-    for (int f = 0; f < frames; f++)
-        if (h_totals[f] > h->cand_cap) return ORBX_CAPACITY;
+    int most = 0;
+    for (int f = 0; f < frames; f++) most = std::max(most, h_totals[f]);
+    if (most > h->cand_cap) {
+        if (regrown) return ORBX_CAPACITY;  // cannot happen: the list was sized for the totals just measured
+        ORBX_TRY(regrow_candidates(h, frames, most));
+        return select_keypoints(h, frames, out, true);
+    }
     size_t total = (size_t)h_offsets[frames];
     ORBX_TRY(h->h_packed.ensure(std::max<size_t>(total, 1)));
     if (total)
@@ -933,9 +964,13 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     int* h_counts = h->h_ints.p;
     for (int f = 0; f < n_frames; f++) {
         // cv::ORB::compute: runByImageBorder on the (possibly moved) keypoints; octaves are already ascending
+        const size_t pre = sel[f].size();
         if (h->has_camera) host::run_by_image_border(sel[f], width, height, h->prm.edge_threshold);
         h_counts[f] = (int)sel[f].size();
         std::copy(sel[f].begin(), sel[f].end(), h->h_kp.p + (size_t)f * capacity);
+        // grid entries of the dropped keypoints name the slots past the new end: a feature no window accepts
+        for (size_t i = sel[f].size(); i < pre; i++)
+            h->h_kp.p[(size_t)f * capacity + i] = orbx_keypoint{0.f, 0.f, 0.f, -1.f, 0.f, -128, -1};
     }
     ORBX_HIP(hipMemcpyAsync(h->d_kp.p, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
                             hipMemcpyHostToDevice, h->stream));

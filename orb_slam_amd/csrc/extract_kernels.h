@@ -1122,9 +1122,13 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
         }
         __syncthreads();
     }
+    // cv::ORB::compute -> runByImageBorder on the moved keypoints; the grid above is left as built, exactly as the
+    // reference leaves it: its entries now name the slots the remaining keypoints moved into, and the last
+    // (pre - count) entries name slots past the end.  The reference reads past the end of its vector there; here
+    // those slots receive a feature no window accepts (octave -128), so the result does not depend on what an earlier
+    // batch left in the buffer.
+    const int pre = count;
     if (fm.has_camera && lvl == 0) {
-        // cv::ORB::compute -> runByImageBorder on the moved keypoints; the grid above is left as built, exactly as
-        // the reference leaves it
         count = compact_ordered(s_kp, count, lane,
                                 [&](const orbx_keypoint& k) { return border_ok(k, fm.width, fm.height, fm.edge); });
         if (lane == 0) s_cnt = count;
@@ -1133,6 +1137,7 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     count = s_cnt;
     orbx_keypoint* out = kps_out + (size_t)b * kp_cap;
     for (int i = tid; i < count; i += blockDim.x) out[i] = s_kp[i];
+    for (int i = count + tid; i < pre; i += blockDim.x) out[i] = orbx_keypoint{0.f, 0.f, 0.f, -1.f, 0.f, -128, -1};
     if (tid == 0) { kp_counts[b] = count; status[b] = 0; }
 }
 
