@@ -151,6 +151,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ransac-pairs", type=int, default=1024)
     ap.add_argument("--streams", type=int, default=2, help="independent batches in flight per GPU")
+    ap.add_argument("--kfdb-frames", type=int, default=1250,
+                    help="frames per GPU of the key-frame database leg (0 = skip): every 10th is a key frame, the "
+                         "ranks all-gather their key frames' descriptors and match every frame against all of them")
+    ap.add_argument("--profile-round", default="r02", help="prefix of the PMC summaries under profiles/ to quote")
     args = ap.parse_args()
 
     import torch
@@ -162,6 +166,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # ORBX_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")
+    backend_is_nccl = backend == "nccl"
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
@@ -311,7 +316,7 @@ def main():
     kernel_of = {"gray": "k_gray_level0", "resize": "k_resize_strip", "fast": "k_fast_nms", "emit": "k_emit",
                  "harris": "k_harris_angle", "blur": "k_blur", "brief": "k_brief"}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", args.profile_round + "_pmc_traffic.json")) as f:
             pmc = json.load(f).get(kernel_of[dom])
         if pmc and pmc.get("frames_per_launch") == B:
             traffic = pmc["traffic_bytes"] * launches[dom]
@@ -371,6 +376,119 @@ def main():
                   "correspondences": n, "stage_ms": rs.last_timings(),
                   "mean_inliers_h": float(d_ih.float().sum(1).mean().item())}
 
+    # ---- issue-rate rooflines of the two halves that are bound by the vector pipes, not by HBM ----------------------
+    # Peaks: nominal = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz lane-operations/s for single-cycle-class instructions
+    # (half of it for fp64); measured = this GPU's sustained rate for the very instruction mix, taken now by
+    # orbx_probe_issue_rate (8 wavefronts per SIMD, independent chains).
+    lanes_nominal = 256 * 4 * 32 * 2.4e9
+    probe = {k: orbx.probe_issue_rate(i, local_rank) * 64 for i, k in
+             enumerate(["add_u32", "xor_bcnt", "mul_add_f64", "mul_add_f32"])}
+    sq = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", args.profile_round + "_pmc_sq.json")) as f:
+            sq = json.load(f)
+    except (OSError, ValueError):
+        pass
+    roofline_ransac = None
+    if ransac:
+        P, n, it = ransac["pairs"], ransac["correspondences"], ransac["iterations"]
+        st = ransac["stage_ms"]
+        # lane-operations of the scorers per (hypothesis, correspondence): Initializer.cpp:410-438 (48 fp64 multiplies,
+        # adds and compares + 2 fp64 divisions) and :552-577 (44 fp32 operations + 2 divisions)
+        def entry(kernel, ms, ops, nominal, measured):
+            e = {"kernel": kernel, "bound": "valu", "ms": ms, "algorithmic_lane_ops": ops,
+                 "achieved": ops / (ms * 1e-3) / 1e12, "peak": nominal / 1e12, "peak_measured": measured / 1e12,
+                 "unit": "T lane-ops/s", "frac": ops / (ms * 1e-3) / nominal,
+                 "frac_of_measured": ops / (ms * 1e-3) / measured,
+                 "note": "duration measured while the other model's kernels share the chip (two streams)"}
+            k = sq.get(kernel)
+            if k and "SQ_INSTS_VALU_per_launch" in k:
+                # every issued vector instruction (address arithmetic, divisions' expansions, LDS traffic included)
+                e["valu_wave_instructions_per_launch"] = k["SQ_INSTS_VALU_per_launch"]
+                e["issue_frac_of_measured"] = k["SQ_INSTS_VALU_per_launch"] * 64 / (ms * 1e-3) / measured
+            return e
+        roofline_ransac = {
+            "score_f_fp64": entry("k_score_f", st["score_f"], float(P) * it * n * 48, lanes_nominal / 2,
+                                  probe["mul_add_f64"]),
+            "score_h_fp32": entry("k_score_h", st["score_h"], float(P) * it * n * 44, lanes_nominal,
+                                  probe["mul_add_f32"]),
+        }
+
+    # brute-force Hamming (cv::BFMatcher of Frame::match): 1024 pairs of 1000 x 1000 descriptors resident in HBM
+    mt = pipes[0].mt
+    HP, HN = 1024, 1000
+    gq = torch.Generator(device=device)
+    gq.manual_seed(99)
+    hq = torch.randint(0, 256, (HP, HN, 32), dtype=torch.uint8, device=device, generator=gq)
+    ht = torch.randint(0, 256, (HP, HN, 32), dtype=torch.uint8, device=device, generator=gq)
+    hn = torch.full((HP,), HN, dtype=torch.int32, device=device)
+    hidx = torch.empty((HP, HN), dtype=torch.int32, device=device)
+    hdist = torch.empty((HP, HN), dtype=torch.int32, device=device)
+
+    def hstep():
+        mt.match_hamming_batch(hq.data_ptr(), hn.data_ptr(), HN * 32, ht.data_ptr(), hn.data_ptr(), HN * 32, HP, HN,
+                               HN, hidx.data_ptr(), hdist.data_ptr(), HN)
+    hstep()
+    he0, he1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    he0.record()
+    for _ in range(5):
+        hstep()
+    he1.record()
+    torch.cuda.synchronize()
+    hms = he0.elapsed_time(he1) / 5
+    hops = float(HP) * HN * HN * 16  # 8 xor + 8 popcount-accumulate per descriptor pair
+    roofline_match = {"kernel": "k_bf_hamming", "bound": "valu", "ms": hms, "pairs_per_s": HP * HN * HN / (hms * 1e-3),
+                      "achieved": hops / (hms * 1e-3) / 1e12, "peak": lanes_nominal / 1e12,
+                      "peak_measured": probe["xor_bcnt"] / 1e12, "unit": "T lane-ops/s",
+                      "frac": hops / (hms * 1e-3) / lanes_nominal,
+                      "frac_of_measured": hops / (hms * 1e-3) / probe["xor_bcnt"],
+                      "workload": f"{HP} pairs of {HN} x {HN} descriptors, 16 lane-operations per descriptor pair",
+                      "note": "v_bcnt_u32_b32 issues at half the rate of v_xor_b32 on gfx950 (probe): the measured "
+                              "peak is the sustained rate of the 1:1 xor/popcount mix"}
+    del hq, ht, hidx, hdist
+
+    # ---- key-frame database leg (BASELINE config 5): the one step of the path with a collective -----------------------
+    kfdb_line = None
+    if args.kfdb_frames > 0:
+        from orb_slam_amd import kfdb
+        KF = args.kfdb_frames
+        kframes, _ = make_sequence(torch, base, KF, rank * KF, device)
+        exk = orbx.Extractor(n_key_points=NKP, level_pyramid=NLEVELS, max_width=W, max_height=H, max_batch=KF,
+                             device=local_rank)
+        exk.set_frame_model(cam, grid)
+        exk.set_stream(stream)
+        mt.set_stream(stream)
+        exk.extract_batch(kframes.data_ptr(), KF, W * H * 3, W, H, W * 3, 3, CAP, to_host=False)
+        kp_ptr, desc_ptr, cnt_ptr, cap = exk.device_results()
+        kdesc = torch.as_tensor(DevView(desc_ptr, (KF, cap, 32), "|u1"), device=device)
+        kcnt = torch.as_tensor(DevView(cnt_ptr, (KF,), "<i4"), device=device)
+        rows = kfdb.keyframe_rows(rank * KF, KF, 10)
+        backend = kfdb.HipBackend(mt)
+        barrier()
+        k0 = time.perf_counter()
+        db_desc, db_counts = kfdb.gather_database(kdesc, kcnt, rows, dist if world > 1 else None)
+        torch.cuda.synchronize()
+        k1 = time.perf_counter()
+        kfdb.match_frames_against_database(backend, kdesc, kcnt, db_desc, db_counts, consume=lambda f, i, d: None)
+        barrier()
+        k2 = time.perf_counter()
+        times = torch.tensor([k1 - k0, k2 - k0], dtype=torch.float64, device=red_device)
+        work = torch.tensor([float(kcnt.double().sum().item())], dtype=torch.float64, device=red_device)
+        if world > 1:
+            dist.all_reduce(times, op=dist.ReduceOp.MAX)
+            dist.all_reduce(work, op=dist.ReduceOp.SUM)
+        db_rows = float(db_counts.double().sum().item())
+        kfdb_line = {"frames_per_gpu": KF, "key_frames_total": int(db_desc.shape[0]),
+                     "database_bytes": int(db_desc.numel()),
+                     "all_gather_ms": float(times[0].item()) * 1e3, "total_ms": float(times[1].item()) * 1e3,
+                     "descriptor_pairs_per_s": float(work.item()) * db_rows / float(times[1].item()),
+                     "collective": "all_gather (RCCL)" if world > 1 and backend_is_nccl else
+                                   ("all_gather (gloo rehearsal)" if world > 1 else "none at 1 GPU"),
+                     "scaling_note": "frames and key frames per GPU fixed; the database every GPU matches against "
+                                     "grows with the number of GPUs"}
+        del kframes, exk
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # up to the whole batch, cut off after about 12 s of CPU work
@@ -388,7 +506,9 @@ def main():
                        "frames_per_gpu_per_step": B, "batches_in_flight": len(pipes), "mean_keypoints": mean_kp,
                        "mean_window_matches": mean_matches,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
-            "roofline": roofline, "ransac": ransac, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_ransac": roofline_ransac, "roofline_match": roofline_match,
+            "ransac": ransac, "extra": {"key_frame_database": kfdb_line, "issue_rate_probe_lane_ops_per_s": probe},
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

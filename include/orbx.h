@@ -351,7 +351,8 @@ orbx_status orbx_triangulate_batch(orbx_ransac* h, int n_pairs, const float* int
    seed per iteration (seed0 + it) in place of std::random_device.  Host arithmetic. */
 orbx_status orbx_ransac_make_sets(int n, int iterations, uint32_t seed0, uint32_t* sets8);
 
-/* Per-kernel launch durations (ms) of the last batch call: normalize, solve, score_f, score_h, select. */
+/* Per-kernel launch durations (ms) of the last batch call: normalize, solve_f, score_f, score_h, select, solve_h
+   (the homography kernels run on a side stream beside the fundamental ones, so the durations overlap). */
 int orbx_ransac_last_timings(const orbx_ransac* h, float* ms, int cap);
 
 /* Test hook (no counterpart in the reference): runs the library's own replay of cv::KeyPointsFilter::retainBest
@@ -361,6 +362,12 @@ orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, in
 /* The same on the device, by the wave-parallel form the batch extractor uses (n <= 8192). */
 orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int n, int n_points, int32_t* perm_out,
                                              int* new_n);
+
+/* Measurement hook (no counterpart in the reference): the vector issue rate this GPU sustains right now, in
+   wave-instructions per second over the whole chip, for one instruction mix: kind 0 = v_add_u32, 1 = v_xor_b32 +
+   v_bcnt_u32_b32 (the Hamming step), 2 = v_mul_f64 + v_add_f64 (un-fused double, the F scorer), 3 = v_mul_f32 +
+   v_add_f32 (the H scorer).  Multiply by 64 for lane-operations per second.  Runs on the NULL stream, about 1 ms. */
+orbx_status orbx_probe_issue_rate(int device, int kind, double* wave_instructions_per_second);
 
 /* Sets the HIP stream (hipStream_t as void*) a handle launches on; NULL restores the handle's own stream. */
 orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream);

@@ -15,9 +15,34 @@ constexpr unsigned long long kNoMatch = ~0ull;
 constexpr int kListCap = 2048;   // candidates of one search window
 constexpr int kMaxFeatures = 8192;  // features per frame the windowed matcher keeps flags for in LDS
 
-// K9: brute-force Hamming, one query per lane (8 dwords in registers), train descriptors staged through LDS in
-// tiles of 256 and broadcast to all lanes.  Packed (distance << 32 | train index) keys make the strict-less,
-// lowest-index-wins rule of cv::BFMatcher a plain minimum, so train chunks can be merged with atomicMin.
+// K9: brute-force Hamming.  A lane holds kHamQ queries (8 dwords each) in registers; train descriptors are staged
+// through LDS in tiles of 256 and broadcast to all lanes, so one pair of 16-byte LDS reads serves kHamQ x 64
+// descriptor pairs (with one query per lane the LDS pipe, shared by the CU's four SIMDs, was nearly as busy as the
+// vector pipes).  Packed (distance << 32 | train index) keys make the strict-less, lowest-index-wins rule of
+// cv::BFMatcher a plain minimum, so train chunks can be merged with atomicMin.
+// popcount(x) + acc in ONE instruction (v_bcnt_u32_b32 adds its second operand).  Left to itself the compiler counts
+// every word into a fresh register and sums them with v_add3_u32: three more half-rate instructions per descriptor pair.
+__device__ __forceinline__ unsigned popc_acc(unsigned x, unsigned acc) {
+    unsigned d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+
+__device__ __forceinline__ unsigned hamming256(const uint4& qa, const uint4& qb, const uint4& a, const uint4& b) {
+    // two chains of four, joined by one add: short enough dependency chains, one extra instruction
+    unsigned d0 = popc_acc(qa.x ^ a.x, 0u), d1 = popc_acc(qb.x ^ b.x, 0u);
+    d0 = popc_acc(qa.y ^ a.y, d0);
+    d1 = popc_acc(qb.y ^ b.y, d1);
+    d0 = popc_acc(qa.z ^ a.z, d0);
+    d1 = popc_acc(qb.z ^ b.z, d1);
+    d0 = popc_acc(qa.w ^ a.w, d0);
+    d1 = popc_acc(qb.w ^ b.w, d1);
+    return d0 + d1;
+}
+
+constexpr int kHamQ = 2;               // queries per lane
+constexpr int kHamBlockQ = 256 * kHamQ;  // queries per workgroup
+
 __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr,
                                                     int nq_const, size_t q_stride, const uint8_t* __restrict__ t,
                                                     const int* __restrict__ nt_arr, int nt_const, size_t t_stride,
@@ -27,19 +52,26 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
     const int p = blockIdx.z;
     const int nq = nq_arr ? nq_arr[p] : nq_const;
     const int nt = nt_arr ? nt_arr[p] : nt_const;
-    const int qi = blockIdx.x * 256 + threadIdx.x;
     const int t0 = blockIdx.y * chunk;
     const int t1 = min(nt, t0 + chunk);
-    if (blockIdx.x * 256 >= nq || t0 >= t1) return;
-    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-    if (qi < nq) {
-        const uint4* qp = (const uint4*)(q + (size_t)p * q_stride + (size_t)qi * 32);
-        qa = qp[0];
-        qb = qp[1];
+    if (blockIdx.x * kHamBlockQ >= nq || t0 >= t1) return;
+    // query j of this lane: blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x (adjacent lanes read adjacent rows)
+    uint4 qa[kHamQ], qb[kHamQ];
+    unsigned best_d[kHamQ];
+    int best_i[kHamQ];
+#pragma unroll
+    for (int j = 0; j < kHamQ; j++) {
+        const int qi = blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x;
+        qa[j] = qb[j] = make_uint4(0, 0, 0, 0);
+        if (qi < nq) {
+            const uint4* qp = (const uint4*)(q + (size_t)p * q_stride + (size_t)qi * 32);
+            qa[j] = qp[0];
+            qb[j] = qp[1];
+        }
+        best_d[j] = 0x7fffffffu;
+        best_i[j] = -1;
     }
     const uint4* tp = (const uint4*)(t + (size_t)p * t_stride);
-    unsigned best_d = 0x7fffffffu;
-    int best_i = -1;
     for (int tb = t0; tb < t1; tb += 256) {
         __syncthreads();
         const int j = tb + threadIdx.x;
@@ -51,16 +83,22 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
         const int cnt = min(256, t1 - tb);
         for (int k = 0; k < cnt; k++) {
             const uint4 a = tile[2 * k], b = tile[2 * k + 1];
-            unsigned d = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
-                         __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
-            if (d < best_d) {
-                best_d = d;
-                best_i = tb + k;
+#pragma unroll
+            for (int u = 0; u < kHamQ; u++) {
+                const unsigned d = hamming256(qa[u], qb[u], a, b);
+                if (d < best_d[u]) {
+                    best_d[u] = d;
+                    best_i[u] = tb + k;
+                }
             }
         }
     }
-    if (qi < nq && best_i >= 0)
-        atomicMin(&best[(size_t)p * best_stride + qi], ((unsigned long long)best_d << 32) | (unsigned)best_i);
+#pragma unroll
+    for (int j = 0; j < kHamQ; j++) {
+        const int qi = blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x;
+        if (qi < nq && best_i[j] >= 0)
+            atomicMin(&best[(size_t)p * best_stride + qi], ((unsigned long long)best_d[j] << 32) | (unsigned)best_i[j]);
+    }
 }
 
 __global__ void k_unpack_best(const unsigned long long* __restrict__ best, size_t best_stride,
@@ -1575,8 +1613,9 @@ orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, co
     ORBX_HIP(hipMemsetAsync(h->d_best.p, 0xff, nb * sizeof(unsigned long long), s));
     const int qb = div_up(max_query, 256);
     if (max_train > 0) {
-        const int chunk = pick_chunk(max_train, qb, n_pairs);
-        dim3 grid(qb, div_up(max_train, chunk), n_pairs);
+        const int hb = div_up(max_query, kHamBlockQ);
+        const int chunk = pick_chunk(max_train, hb, n_pairs);
+        dim3 grid(hb, div_up(max_train, chunk), n_pairs);
         hipLaunchKernelGGL(k_bf_hamming, grid, dim3(256), 0, s, d_query, d_n_query, max_query, query_stride, d_train,
                            d_n_train, max_train, train_stride, chunk, h->d_best.p, (size_t)max_query);
     }

@@ -11,7 +11,7 @@
 using namespace orbx;
 
 namespace {
-enum Stage { RT_NORMALIZE = 0, RT_SOLVE, RT_SCORE_F, RT_SCORE_H, RT_SELECT, RT_COUNT };
+enum Stage { RT_NORMALIZE = 0, RT_SOLVE, RT_SCORE_F, RT_SCORE_H, RT_SELECT, RT_SOLVE_H, RT_COUNT };
 }
 
 struct orbx_ransac {
@@ -84,9 +84,11 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
     hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, w.pn, w.rn, n, w.T, d_sets8,
                        iterations, pairs, w.Fall, w.bad);
     T.end(RT_SOLVE, s);
-    T.begin(RT_SCORE_H, sh);
+    T.begin(RT_SOLVE_H, sh);
     hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, sh, w.pn, w.rn, n, w.T, d_sets8,
                        iterations, pairs, w.Hall, w.Hiall);
+    T.end(RT_SOLVE_H, sh);
+    T.begin(RT_SCORE_H, sh);
     T.begin(RT_SCORE_F, s);
     if (flat)
         hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, w.Fall, iterations,

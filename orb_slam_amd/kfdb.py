@@ -1,0 +1,103 @@
+"""Key-frame descriptor database: many-to-many brute-force Hamming matching over all ranks' key frames.
+
+Every rank extracts its own contiguous block of frames (no collective on that path).  Every `every`-th frame of the
+sequence is a key frame; the ranks replicate their key frames' descriptor blocks with ONE all-gather of uint8 rows
+(RCCL over xGMI on GPUs, gloo on CPU) plus one of the per-key-frame row counts, and then each rank matches each of
+its frames against every key frame of the database: per (frame, key frame) pair what CVORBMatcher::match returns
+(reference src/geometry/orb_matcher.cpp:671-677: for every query row the train row of minimum Hamming distance,
+lowest index on ties).
+
+The matching call is a backend object, so that the same driver runs on the GPU (HipBackend: the C ABI's
+orbx_match_hamming_batch, one call per frame with the query block shared by all pairs) and in the CPU tests of the
+multi-rank path (a stand-in backend with the same contract).
+"""
+import numpy as np
+
+
+def keyframe_rows(first_global_index, n_local, every=10):
+    """Local indices of the key frames among frames first_global_index .. first_global_index + n_local - 1."""
+    first = (-first_global_index) % every
+    return list(range(first, n_local, every))
+
+
+def gather_database(desc, counts, key_rows, dist=None):
+    """desc: [frames, cap, 32] uint8 tensor, counts: [frames] int32 tensor (same device), key_rows: local indices.
+    Returns (db_desc [K, cap, 32], db_counts [K]) holding the key frames of all ranks in rank order.  Every rank must
+    contribute the same number of key frames (the sequence is dealt in equal blocks)."""
+    import torch
+    rows = torch.as_tensor(key_rows, dtype=torch.long, device=desc.device)
+    local_desc = desc.index_select(0, rows).contiguous()
+    local_counts = counts.index_select(0, rows).contiguous()
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_desc, local_counts
+    world = dist.get_world_size()
+    out_d = [torch.empty_like(local_desc) for _ in range(world)]
+    out_c = [torch.empty_like(local_counts) for _ in range(world)]
+    dist.all_gather(out_d, local_desc)
+    dist.all_gather(out_c, local_counts)
+    return torch.cat(out_d, 0), torch.cat(out_c, 0)
+
+
+class HipBackend:
+    """orbx_match_hamming_batch on device tensors: pair k of a call = (the frame's rows, key frame k's rows)."""
+
+    def __init__(self, matcher):
+        self.matcher = matcher
+
+    def match(self, query, n_query_rep, db_desc, db_counts, out_idx, out_dist):
+        """query [cap, 32]; n_query_rep [K] (the frame's row count repeated); outputs [K, cap] int32."""
+        K, cap = db_desc.shape[0], db_desc.shape[1]
+        self.matcher.match_hamming_batch(query.data_ptr(), n_query_rep.data_ptr(), 0, db_desc.data_ptr(),
+                                         db_counts.data_ptr(), cap * 32, K, cap, cap, out_idx.data_ptr(),
+                                         out_dist.data_ptr(), cap)
+
+
+class NumpyBackend:
+    """The same contract on CPU tensors (tests of the multi-rank driver; never the thing measured)."""
+
+    _POP = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+    def match(self, query, n_query_rep, db_desc, db_counts, out_idx, out_dist):
+        q = query.numpy()
+        for k in range(db_desc.shape[0]):
+            nq, nt = int(n_query_rep[k]), int(db_counts[k])
+            if nq == 0:
+                continue
+            if nt == 0:
+                out_idx[k, :nq] = -1
+                out_dist[k, :nq] = -1
+                continue
+            t = db_desc[k, :nt].numpy()
+            d = self._POP[q[:nq, None, :] ^ t[None, :, :]].sum(2)
+            best = d.argmin(1)  # first minimum: lowest train index on ties
+            import torch
+            out_idx[k, :nq] = torch.from_numpy(best.astype(np.int32))
+            out_dist[k, :nq] = torch.from_numpy(d[np.arange(nq), best].astype(np.int32))
+
+
+def match_frames_against_database(backend, desc, counts, db_desc, db_counts, frames=None, consume=None):
+    """Matches each local frame (all, or the indices in `frames`) against every key frame of the database.
+    consume(frame, idx [K, cap], dist [K, cap]) is called per frame with buffers that are reused by the next frame;
+    without it the per-frame results are stacked and returned as ([frames, K, cap], [frames, K, cap]), -1 in the rows
+    past a frame's count.  On the GPU the matcher must launch on the stream torch is using (Matcher.set_stream)."""
+    import torch
+    K, cap = db_desc.shape[0], db_desc.shape[1]
+    frames = list(range(desc.shape[0])) if frames is None else list(frames)
+    n_rep = counts[:, None].expand(counts.shape[0], K).contiguous()
+    out_idx = torch.zeros((K, cap), dtype=torch.int32, device=desc.device)
+    out_dist = torch.zeros((K, cap), dtype=torch.int32, device=desc.device)
+    kept_i, kept_d = [], []
+    for f in frames:
+        if consume is None:
+            # rows past a frame's count are not written by the matcher: give them one value for every frame
+            out_idx.fill_(-1)
+            out_dist.fill_(-1)
+        backend.match(desc[f], n_rep[f], db_desc, db_counts, out_idx, out_dist)
+        if consume is not None:
+            consume(f, out_idx, out_dist)
+        else:
+            kept_i.append(out_idx.clone())
+            kept_d.append(out_dist.clone())
+    if consume is not None:
+        return None
+    return torch.stack(kept_i), torch.stack(kept_d)

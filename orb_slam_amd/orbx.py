@@ -31,7 +31,7 @@ SYMBOLS = [
     "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
-    "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+    "orbx_probe_issue_rate", "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
 
@@ -546,6 +546,13 @@ def selftest_retain_best_device(keys, n_points, device=0):
     return perm[:n.value].copy()
 
 
+def probe_issue_rate(kind, device=0):
+    """Wave-instructions per second of the chip for one instruction mix (orbx_probe_issue_rate)."""
+    v = C.c_double()
+    _check(lib().orbx_probe_issue_rate(device, kind, C.byref(v)), "orbx_probe_issue_rate")
+    return v.value
+
+
 def ransac_make_sets(n, iterations, seed0):
     out = np.zeros((iterations, 8), np.uint32)
     _check(lib().orbx_ransac_make_sets(n, iterations, C.c_uint32(seed0), _p(out)), "orbx_ransac_make_sets")
@@ -648,9 +655,9 @@ class Ransac:
                "orbx_ransac_fh_batch_static")
 
     def last_timings(self):
-        ms = np.zeros(5, np.float32)
-        n = lib().orbx_ransac_last_timings(self._h, _p(ms), 5)
-        names = ["normalize", "solve_f", "score_f", "solve_h+score_h_side_stream", "select"]
+        ms = np.zeros(6, np.float32)
+        n = lib().orbx_ransac_last_timings(self._h, _p(ms), 6)
+        names = ["normalize", "solve_f", "score_f", "score_h", "select", "solve_h"]
         return dict(zip(names[:n], ms[:n].tolist()))
 
 

@@ -74,6 +74,74 @@ def test_two_rank_shards_equal_single_process():
     assert full[:, 0, 0].tolist() == [0, 1, 2, 3, 4, 5] and full[3:, :, 1].min() == 1 and full[:3, :, 1].max() == 0
 
 
+def _kfdb_descriptors(first, n, cap):
+    """Deterministic per-frame descriptor blocks keyed by the GLOBAL frame index (so any sharding sees the same data):
+    frame g has 40 + (7 g mod 17) rows; consecutive frames share most rows, as consecutive video frames do."""
+    import torch
+    base = np.random.default_rng(1234).integers(0, 256, (cap + 64, 32), dtype=np.uint8)
+    desc = np.zeros((n, cap, 32), np.uint8)
+    counts = np.zeros(n, np.int32)
+    for i in range(n):
+        g = first + i
+        counts[i] = 40 + (7 * g) % 17
+        rows = base[g % 5:g % 5 + counts[i]].copy()
+        flip = np.random.default_rng(g).integers(0, 256, rows.shape, dtype=np.uint8) & 0x11
+        desc[i, :counts[i]] = rows ^ flip
+    return torch.from_numpy(desc), torch.from_numpy(counts)
+
+
+def _kfdb_worker(rank, world, port, n_frames, cap, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from orb_slam_amd import kfdb
+    from orb_slam_amd.shard import shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_frames, rank, world)
+    desc, counts = _kfdb_descriptors(lo, hi - lo, cap)
+    db_desc, db_counts = kfdb.gather_database(desc, counts, kfdb.keyframe_rows(lo, hi - lo, 10), dist)
+    idx, dd = kfdb.match_frames_against_database(kfdb.NumpyBackend(), desc, counts, db_desc, db_counts)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, db_counts.numpy(), idx.numpy(), dd.numpy()))
+    dist.barrier()
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_keyframe_database_two_ranks_equal_single_process():
+    """The key-frame database step (all-gather of the ranks' key-frame descriptor blocks, then every local frame
+    against the whole database) through the same driver functions the GPU path uses (orb_slam_amd/kfdb.py), with a
+    CPU stand-in only for the matching call: two gloo ranks give, concatenated in frame order, what one process gives."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from orb_slam_amd import kfdb
+    n_frames, world, cap = 40, 2, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kfdb_worker, args=(r, world, port, n_frames, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    desc, counts = _kfdb_descriptors(0, n_frames, cap)
+    rows = kfdb.keyframe_rows(0, n_frames, 10)
+    assert rows == [0, 10, 20, 30]
+    db_desc, db_counts = kfdb.gather_database(desc, counts, rows)
+    idx, dd = kfdb.match_frames_against_database(kfdb.NumpyBackend(), desc, counts, db_desc, db_counts)
+    assert gathered[0][0] == 0 and gathered[0][1] == gathered[1][0] and gathered[1][1] == n_frames
+    for _, _, dbc, _, _ in gathered:
+        assert np.array_equal(dbc, db_counts.numpy())       # every rank holds the whole database, in rank order
+    assert np.array_equal(np.concatenate([g[3] for g in gathered]), idx.numpy())
+    assert np.array_equal(np.concatenate([g[4] for g in gathered]), dd.numpy())
+    # a frame that is a key frame matches its own database entry exactly
+    assert (dd.numpy()[10, 1, :counts[10]] == 0).all() and (idx.numpy()[10, 1, :counts[10]] == np.arange(counts[10])).all()
+
+
 def test_shard_range_covers_everything():
     from orb_slam_amd.shard import shard_range
     for n in (0, 1, 7, 10000):

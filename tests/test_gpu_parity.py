@@ -290,6 +290,59 @@ def test_match_hamming_bit_exact(oracle, matcher, ex1000, test_images):
     assert len(set(m["train"][1:].tolist())) == len(m) - 1
 
 
+def test_match_hamming_batch_ragged_pairs(oracle, matcher):
+    """orbx_match_hamming_batch on several pairs of ragged sizes in one call (empty query or train sets, sizes around
+    the 256-row tiles and the 512-query blocks, many equal rows: ties must go to the lowest train index), against the
+    oracle pair by pair; then the key-frame database driver (one call per frame, the query block shared by all pairs)
+    against its CPU stand-in."""
+    import torch
+    from orb_slam_amd import kfdb
+    rng = np.random.default_rng(61)
+    sizes = [(0, 10), (10, 0), (1, 1), (255, 257), (256, 256), (257, 255), (511, 513), (512, 512), (513, 1000),
+             (1000, 999), (300, 2)]
+    cap_q, cap_t = 1000, 1000
+    P = len(sizes)
+    q = np.zeros((P, cap_q, 32), np.uint8)
+    t = np.zeros((P, cap_t, 32), np.uint8)
+    for p, (nq, nt) in enumerate(sizes):
+        t[p, :nt] = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        if nt:
+            t[p, :nt:3] = t[p, 0]                                    # every third train row identical: ties
+            q[p, :nq] = t[p, rng.integers(0, nt, nq)] ^ (rng.integers(0, 256, (nq, 32), dtype=np.uint8) & 0x05)
+        else:
+            q[p, :nq] = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    d_q, d_t = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    d_nq = torch.tensor([a for a, _ in sizes], dtype=torch.int32, device="cuda")
+    d_nt = torch.tensor([b for _, b in sizes], dtype=torch.int32, device="cuda")
+    d_idx = torch.full((P, cap_q), -7, dtype=torch.int32, device="cuda")
+    d_dist = torch.full((P, cap_q), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    matcher.match_hamming_batch(d_q.data_ptr(), d_nq.data_ptr(), cap_q * 32, d_t.data_ptr(), d_nt.data_ptr(),
+                                cap_t * 32, P, cap_q, cap_t, d_idx.data_ptr(), d_dist.data_ptr(), cap_q)
+    torch.cuda.synchronize()
+    idx, dist = d_idx.cpu().numpy(), d_dist.cpu().numpy()
+    for p, (nq, nt) in enumerate(sizes):
+        if nt == 0:
+            assert (idx[p, :nq] == -1).all()
+        else:
+            oi, od = oracle.match_hamming(q[p, :nq], t[p, :nt])
+            assert np.array_equal(idx[p, :nq], oi) and np.array_equal(dist[p, :nq], od), (p, nq, nt)
+        assert (idx[p, nq:] == -7).all()                              # rows past a pair's count are not written
+    # the key-frame database driver: 6 frames against 4 key frames
+    desc = torch.from_numpy(q[3:9, :600].copy())
+    counts = torch.tensor([255, 256, 257, 511, 512, 513], dtype=torch.int32)
+    db_desc, db_counts = kfdb.gather_database(desc, counts, [0, 2, 3, 5])
+    want_i, want_d = kfdb.match_frames_against_database(kfdb.NumpyBackend(), desc, counts, db_desc, db_counts)
+    matcher.set_stream(torch.cuda.current_stream().cuda_stream)
+    got_i, got_d = kfdb.match_frames_against_database(kfdb.HipBackend(matcher), desc.cuda(), counts.cuda(),
+                                                      db_desc.cuda(), db_counts.cuda())
+    torch.cuda.synchronize()
+    matcher.set_stream(0)
+    for f in range(6):
+        n = int(counts[f])
+        assert torch.equal(got_i[f, :, :n].cpu(), want_i[f, :, :n]) and torch.equal(got_d[f, :, :n].cpu(), want_d[f, :, :n])
+
+
 def test_match_radius_bit_exact(oracle, matcher, ex8000, test_images):
     r = [ex8000.compute(img, ex8000.detect(img)) for img in test_images]
     for radius in (100.0, 12.5, 0.0):
