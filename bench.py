@@ -222,10 +222,8 @@ def main():
         def step(self, record=False):
             ex, mt = self.ex, self.mt
             with torch.cuda.stream(self.tstream):
-                ex.extract_batch(frames.data_ptr(), B, W * H * 3, W, H, W * 3, 3, CAP, to_host=False)
-                if record:
-                    for k, v in ex.last_timings().items():
-                        stage_ms.setdefault(k, []).append(v)
+                # queued, not waited for: the matcher below consumes the device results on the same stream
+                ex.extract_batch(frames.data_ptr(), B, W * H * 3, W, H, W * 3, 3, CAP, to_host=False, deferred=True)
                 kp_ptr, desc_ptr, cnt_ptr, cap = ex.device_results()
                 cs_ptr, ci_ptr = ex.device_grid()
                 kp = torch.as_tensor(DevView(kp_ptr, (B, cap, 7), "<f4"), device=device)
@@ -241,7 +239,12 @@ def main():
                                                 self.d_nm.data_ptr())
                 e1.record()
                 self.tstream.synchronize()  # the batch's results are complete when step() returns
+                _, redone = ex.finish()     # status of the extraction (capacity, host-selection fallback)
+                if redone:
+                    raise RuntimeError("a frame fell back to the host selection: the match above ran on stale keypoints")
                 if record:
+                    for k, v in ex.last_timings().items():
+                        stage_ms.setdefault(k, []).append(v)
                     match_ms.append((e0, e1))
 
     pipes = [Pipeline() for _ in range(max(1, args.streams))]

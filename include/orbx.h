@@ -77,7 +77,12 @@ orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int 
 
 /* Replaces ORBExtractor::compute (orb_extractor.h:113-119 -> cv::ORB::compute).  keypoints is filtered and,
    when not sorted by octave, regrouped in place exactly as cv::ORB does; *count is updated; descriptors
-   receives *count rows of 32 bytes. */
+   receives *count rows of 32 bytes.
+   MonoFrame::extractFeatures calls detect and then compute on the same image (src/mono_frame.cpp:75,102), where
+   cv::ORB builds the pyramid twice.  Here the handle remembers the image of its last detect / compute (address,
+   geometry and a hash of every (height / 48)-th row) and a compute on that image finds the upload and the pyramid
+   still on the device.  A caller that rewrites pixels of the same buffer between the two calls in rows the hash
+   does not sample must switch the reuse off (orbx_extractor_set_image_cache); results are identical either way. */
 orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
                          orbx_keypoint* keypoints, int* count, uint8_t* descriptors);
 
@@ -89,6 +94,20 @@ orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int
 orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n_frames, size_t frame_stride,
                                int width, int height, int stride, int channels,
                                orbx_keypoint* keypoints, int capacity, int32_t* counts, uint8_t* descriptors);
+
+/* With keypoints, counts and descriptors all NULL, orbx_extract_batch returns as soon as its kernels are queued on
+   the handle's stream: the device results (orbx_extractor_device_results / _device_grid) may be consumed by work
+   queued on the same stream right away, and the host never waits inside the call.  orbx_extractor_finish then waits
+   for that batch and reports what the synchronous call would have returned: ORBX_CAPACITY when a frame has more
+   keypoints than `capacity`; counts[n_frames] when non-NULL.  *redone = 1 (when non-NULL) says that a frame had
+   more candidates than the on-device selection holds and the batch was finished by the host selection inside this
+   call: the device results are now the final ones, and whatever consumed them before has to run again.  A batch
+   that was never finished is waited for and dropped by the next call on the handle.  No counterpart in the
+   reference (its extraction is synchronous). */
+orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redone);
+
+/* Switches the reuse of the uploaded image and its pyramid between orbx_detect and orbx_compute (default on). */
+orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled);
 
 /* Camera model of Camera::undistortPoints (src/geometry/camera.cpp:97-126 -> cv::undistortPoints with P = K).
    Intrinsics and distortion as the reference holds them (cv::Mat_<float> widened to double). */

@@ -90,6 +90,28 @@ struct orbx_extractor {
     int last_frames = 0;
     bool pyramid_valid = false;  // atlas holds the pyramid of the frames of the last detect stage
 
+    // detect() followed by compute() on the same image (MonoFrame::extractFeatures, mono_frame.cpp:75,102): the
+    // second call finds the uploaded image and its pyramid still on the device
+    struct ImageKey {
+        const void* ptr = nullptr;
+        int w = 0, h = 0, stride = 0, ch = 0;
+        uint64_t sample = 0;
+        bool valid = false;
+    } cached_image;
+    bool image_cache_enabled = true;
+
+    // a batch whose caller asked for no host copies returns before the GPU has finished; its status words are
+    // looked at by orbx_extractor_finish (or dropped by the next call on the handle)
+    struct Pending {
+        bool active = false;
+        const uint8_t* d_images = nullptr;
+        int n_frames = 0;
+        size_t frame_stride = 0;
+        int width = 0, height = 0, stride = 0, channels = 0, capacity = 0;
+    } pending;
+    hipEvent_t ev_done = nullptr;
+    std::vector<int32_t> last_counts;  // keypoints per frame of the last finished batch
+
     StageTimer timer;
     float last_ms[ST_COUNT] = {};
 };
@@ -317,6 +339,51 @@ struct BlurForkGuard {
     orbx_extractor* h;
     ~BlurForkGuard() { join_blur_fork(h); }
 };
+
+// Fingerprint of a host image for the detect -> compute pyramid reuse: its address, geometry and a hash of every
+// h/48-th row (about 2 % of the bytes, a few microseconds; hashing everything would cost what the reuse saves).
+uint64_t sample_rows(const uint8_t* image, int w, int hgt, int stride, int ch) {
+    const size_t row_bytes = (size_t)w * ch;
+    const int step = std::max(1, hgt / 48);
+    uint64_t acc[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+    auto row = [&](int y) {
+        const uint8_t* p = image + (size_t)y * stride;
+        size_t i = 0;
+        for (; i + 32 <= row_bytes; i += 32) {
+            uint64_t v[4];
+            std::memcpy(v, p + i, 32);
+            for (int k = 0; k < 4; k++) acc[k] = (acc[k] ^ v[k]) * 0x100000001b3ull + (acc[k] >> 29);
+        }
+        for (; i < row_bytes; i++) acc[i & 3] = (acc[i & 3] ^ p[i]) * 0x100000001b3ull;
+    };
+    for (int y = 0; y < hgt; y += step) row(y);
+    row(hgt - 1);
+    return acc[0] ^ (acc[1] << 1) ^ (acc[2] << 2) ^ (acc[3] << 3);
+}
+
+bool same_image(const orbx_extractor* h, const uint8_t* image, int w, int hgt, int stride, int ch, uint64_t sample) {
+    const orbx_extractor::ImageKey& k = h->cached_image;
+    return h->image_cache_enabled && k.valid && h->pyramid_valid && k.ptr == image && k.w == w && k.h == hgt &&
+           k.stride == stride && k.ch == ch && k.sample == sample;
+}
+
+void remember_image(orbx_extractor* h, const uint8_t* image, int w, int hgt, int stride, int ch, uint64_t sample) {
+    h->cached_image.ptr = image;
+    h->cached_image.w = w;
+    h->cached_image.h = hgt;
+    h->cached_image.stride = stride;
+    h->cached_image.ch = ch;
+    h->cached_image.sample = sample;
+    h->cached_image.valid = true;
+}
+
+// A deferred batch (see orbx_extractor_finish) that the caller never finished: wait for it and drop it.
+orbx_status drain_pending(orbx_extractor* h) {
+    if (!h->pending.active) return ORBX_OK;
+    h->pending.active = false;
+    ORBX_HIP(hipEventSynchronize(h->ev_done));
+    return ORBX_OK;
+}
 
 // Launch shape of k_gray_level0: x covers the larger of its two regions (interior 16-pixel groups, edge pixels).
 dim3 gray_grid(const Geom& g, int w, int hgt, int frames) {
@@ -585,7 +652,8 @@ orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_w
     h->stream = h->own_stream;
     if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_pyramid, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) {
         orbx_extractor_destroy(h);
         return ORBX_DEVICE;
     }
@@ -661,6 +729,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
     if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
     if (h->ev_blur) (void)hipEventDestroy(h->ev_blur);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -702,6 +771,7 @@ orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, ui
     if (!h || !out || frame < 0 || frame >= std::max(h->last_frames, 1)) return ORBX_BAD_ARG;
     if (out_bytes < h->atlas_bytes) return ORBX_CAPACITY;
     ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(drain_pending(h));
     const uint8_t* src = what == 0 ? h->d_atlas.p : what == 1 ? h->d_score.p : what == 2 ? h->d_blur.p : nullptr;
     if (!src) return ORBX_BAD_ARG;
     if (what == 1) {
@@ -753,13 +823,17 @@ orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int 
     *count = 0;
     ORBX_TRY(check_image_args(h, image, width, height, stride, channels));
     ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(drain_pending(h));
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
     ORBX_TRY(ensure_buffers(h, 1));
     size_t bytes = (size_t)stride * height;
     ORBX_TRY(h->d_in.ensure(bytes));
+    h->cached_image.valid = false;
     ORBX_HIP(hipMemcpyAsync(h->d_in.p, image, bytes, hipMemcpyHostToDevice, h->stream));
     h->last_frames = 1;
     ORBX_TRY(run_detect_stage(h, h->d_in.p, 1, bytes, width, height, stride, channels));
+    if (h->image_cache_enabled)
+        remember_image(h, image, width, height, stride, channels, sample_rows(image, width, height, stride, channels));
     std::vector<std::vector<orbx_keypoint>> sel;
     ORBX_TRY(select_keypoints(h, 1, sel));
     collect_timings(h);
@@ -791,14 +865,24 @@ orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int
     if (k.empty()) { *count = 0; return ORBX_OK; }
 
     ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(drain_pending(h));
+    // a geometry change (more levels than the extractor's own) invalidates the cached pyramid by itself
     ORBX_TRY(build_geometry(h, width, height, std::max(nlevels, h->prm.level_pyramid)));
     ORBX_TRY(ensure_buffers(h, 1));
     size_t bytes = (size_t)stride * height;
-    ORBX_TRY(h->d_in.ensure(bytes));
-    ORBX_HIP(hipMemcpyAsync(h->d_in.p, image, bytes, hipMemcpyHostToDevice, h->stream));
     h->last_frames = 1;
     h->timer.clear();
-    ORBX_TRY(run_pyramid(h, h->d_in.p, 1, bytes, width, height, stride, channels));
+    const uint64_t sample = h->image_cache_enabled ? sample_rows(image, width, height, stride, channels) : 0;
+    if (same_image(h, image, width, height, stride, channels, sample)) {
+        join_blur_fork(h);  // nothing to upload, nothing to build: the pyramid of this image is in the atlas
+    } else {
+        ORBX_TRY(h->d_in.ensure(bytes));
+        h->cached_image.valid = false;
+        ORBX_HIP(hipMemcpyAsync(h->d_in.p, image, bytes, hipMemcpyHostToDevice, h->stream));
+        ORBX_TRY(run_pyramid(h, h->d_in.p, 1, bytes, width, height, stride, channels));
+        h->pyramid_valid = true;
+        if (h->image_cache_enabled) remember_image(h, image, width, height, stride, channels, sample);
+    }
     int m = (int)k.size();
     if (m > h->kp_cap) h->kp_cap = m;
     ORBX_TRY(h->d_kp.ensure((size_t)h->kp_cap));
@@ -815,6 +899,97 @@ orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int
     return ORBX_OK;
 }
 
+}  // extern "C"
+
+// orbx_extract_batch from the selection on, by the host path: candidates are downloaded, cv::ORB's two retainBest
+// culls run with the real std:: calls, then undistortion, grid and border filter as MonoFrame::extractFeatures does
+// them (mono_frame.cpp:85-100), and the keypoints go back to the device for the describe stage.  No limit on
+// candidates or keypoint slots.  The detect stage of the batch must be what the device buffers hold.
+static orbx_status batch_host_path(orbx_extractor* h, int n_frames, int width, int height, int capacity,
+                                   orbx_keypoint* keypoints, int32_t* counts, uint8_t* descriptors) {
+    std::vector<std::vector<orbx_keypoint>> sel;
+    ORBX_TRY(select_keypoints(h, n_frames, sel));
+    // MonoFrame::extractFeatures between detect and compute (mono_frame.cpp:85-100): undistort, bucket, filter
+    const int ncell = h->has_grid ? h->grid.grid_cols * h->grid.grid_rows : 0;
+    if (h->has_grid) {
+        ORBX_TRY(h->h_cell_start.ensure((size_t)(ncell + 1) * n_frames));
+        ORBX_TRY(h->h_cell_items.ensure((size_t)capacity * n_frames));
+    }
+    int max_n = 0;
+    for (auto& v : sel) max_n = std::max(max_n, (int)v.size());
+    if (max_n > capacity) return ORBX_CAPACITY;
+    if (h->has_camera || h->has_grid) {
+        auto work = [&](int f0, int f1) {
+            std::vector<float> xy;
+            for (int f = f0; f < f1; f++) {
+                auto& k = sel[f];
+                if (h->has_camera && h->camera.k1 != 0.0 && !k.empty()) {
+                    xy.resize(k.size() * 2);
+                    for (size_t i = 0; i < k.size(); i++) { xy[2 * i] = k[i].x; xy[2 * i + 1] = k[i].y; }
+                    host::undistort_points(h->camera, xy.data(), (int)k.size(), xy.data());
+                    for (size_t i = 0; i < k.size(); i++) { k[i].x = xy[2 * i]; k[i].y = xy[2 * i + 1]; }
+                }
+                if (h->has_grid) {
+                    int cnt = (int)k.size();
+                    (void)orbx_assign_grid(&h->grid, k.data(), &cnt, h->h_cell_start.p + (size_t)f * (ncell + 1),
+                                           h->h_cell_items.p + (size_t)f * capacity);
+                    k.resize(cnt);
+                }
+                // cv::ORB::compute drops keypoints whose rounded position is within the border (it may, after
+                // undistortion); the grid built above then refers to the unfiltered list, as in the reference.
+            }
+        };
+        int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+        nthreads = std::min(nthreads, n_frames);
+        std::vector<std::thread> th;
+        int per = div_up(n_frames, nthreads);
+        for (int t = 0; t < nthreads; t++) {
+            int f0 = t * per, f1 = std::min(n_frames, f0 + per);
+            if (f0 < f1) th.emplace_back(work, f0, f1);
+        }
+        for (auto& t : th) t.join();
+    }
+    h->kp_cap = capacity;
+    ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
+    ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
+    ORBX_TRY(h->d_kp_counts.ensure(n_frames));
+    ORBX_TRY(h->h_kp.ensure((size_t)capacity * n_frames));
+    int* h_counts = h->h_ints.p;
+    for (int f = 0; f < n_frames; f++) {
+        // cv::ORB::compute: runByImageBorder on the (possibly moved) keypoints; octaves are already ascending
+        const size_t pre = sel[f].size();
+        if (h->has_camera) host::run_by_image_border(sel[f], width, height, h->prm.edge_threshold);
+        h_counts[f] = (int)sel[f].size();
+        std::copy(sel[f].begin(), sel[f].end(), h->h_kp.p + (size_t)f * capacity);
+        // grid entries of the dropped keypoints name the slots past the new end: a feature no window accepts
+        for (size_t i = sel[f].size(); i < pre; i++)
+            h->h_kp.p[(size_t)f * capacity + i] = orbx_keypoint{0.f, 0.f, 0.f, -1.f, 0.f, -128, -1};
+    }
+    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
+                            hipMemcpyHostToDevice, h->stream));
+    ORBX_HIP(hipMemcpyAsync(h->d_kp_counts.p, h_counts, sizeof(int) * n_frames, hipMemcpyHostToDevice, h->stream));
+    if (h->has_grid) {
+        ORBX_TRY(h->d_cell_start.ensure((size_t)(ncell + 1) * n_frames));
+        ORBX_TRY(h->d_cell_items.ensure((size_t)capacity * n_frames));
+        ORBX_HIP(hipMemcpyAsync(h->d_cell_start.p, h->h_cell_start.p, sizeof(int32_t) * (size_t)(ncell + 1) * n_frames,
+                                hipMemcpyHostToDevice, h->stream));
+        ORBX_HIP(hipMemcpyAsync(h->d_cell_items.p, h->h_cell_items.p, sizeof(int32_t) * (size_t)capacity * n_frames,
+                                hipMemcpyHostToDevice, h->stream));
+    }
+    ORBX_TRY(run_describe_stage(h, n_frames));
+    if (descriptors)
+        ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost,
+                                h->stream));
+    ORBX_HIP(hipStreamSynchronize(h->stream));
+    collect_timings(h);
+    h->last_counts.assign(h_counts, h_counts + n_frames);
+    if (counts) std::memcpy(counts, h_counts, sizeof(int) * n_frames);
+    if (keypoints) std::memcpy(keypoints, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames);
+    return ORBX_OK;
+}
+
+extern "C" {
+
 orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n_frames, size_t frame_stride,
                                int width, int height, int stride, int channels, orbx_keypoint* keypoints,
                                int capacity, int32_t* counts, uint8_t* descriptors) {
@@ -822,6 +997,8 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     if (n_frames <= 0 || capacity <= 0 || frame_stride < (size_t)stride * height) return ORBX_BAD_ARG;
     if (n_frames > h->max_batch) return ORBX_CAPACITY;
     ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(drain_pending(h));
+    h->cached_image.valid = false;
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
     ORBX_TRY(ensure_buffers(h, n_frames));
     h->last_frames = n_frames;
@@ -901,6 +1078,21 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         if (descriptors)
             ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost,
                                     h->stream));
+        if (!keypoints && !descriptors && !counts) {
+            // nothing to hand to the host: the call returns with the work queued; orbx_extractor_finish looks at the
+            // status words (the device results may be consumed on the same stream before that)
+            ORBX_HIP(hipEventRecord(h->ev_done, h->stream));
+            h->pending.active = true;
+            h->pending.d_images = d_images;
+            h->pending.n_frames = n_frames;
+            h->pending.frame_stride = frame_stride;
+            h->pending.width = width;
+            h->pending.height = height;
+            h->pending.stride = stride;
+            h->pending.channels = channels;
+            h->pending.capacity = capacity;
+            return ORBX_OK;
+        }
         ORBX_HIP(hipStreamSynchronize(h->stream));
         collect_timings(h);
         bool redo = false;
@@ -909,89 +1101,44 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
             if (h_status[f] == 2) redo = true;
         }
         if (!redo) {
+            h->last_counts.assign(h_cnt, h_cnt + n_frames);
             if (counts) std::memcpy(counts, h_cnt, sizeof(int) * n_frames);
             return ORBX_OK;
         }
     }
+    return batch_host_path(h, n_frames, width, height, capacity, keypoints, counts, descriptors);
+}
 
-    std::vector<std::vector<orbx_keypoint>> sel;
-    ORBX_TRY(select_keypoints(h, n_frames, sel));
-    // MonoFrame::extractFeatures between detect and compute (mono_frame.cpp:85-100): undistort, bucket, filter
-    const int ncell = h->has_grid ? h->grid.grid_cols * h->grid.grid_rows : 0;
-    if (h->has_grid) {
-        ORBX_TRY(h->h_cell_start.ensure((size_t)(ncell + 1) * n_frames));
-        ORBX_TRY(h->h_cell_items.ensure((size_t)capacity * n_frames));
+orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redone) {
+    if (!h) return ORBX_BAD_ARG;
+    if (redone) *redone = 0;
+    if (!h->pending.active) {
+        // the batch was completed inside orbx_extract_batch (host selection): only the counts are left to hand over
+        if (counts && !h->last_counts.empty()) std::memcpy(counts, h->last_counts.data(), sizeof(int32_t) * h->last_counts.size());
+        return ORBX_OK;
     }
-    int max_n = 0;
-    for (auto& v : sel) max_n = std::max(max_n, (int)v.size());
-    if (max_n > capacity) return ORBX_CAPACITY;
-    if (h->has_camera || h->has_grid) {
-        auto work = [&](int f0, int f1) {
-            std::vector<float> xy;
-            for (int f = f0; f < f1; f++) {
-                auto& k = sel[f];
-                if (h->has_camera && h->camera.k1 != 0.0 && !k.empty()) {
-                    xy.resize(k.size() * 2);
-                    for (size_t i = 0; i < k.size(); i++) { xy[2 * i] = k[i].x; xy[2 * i + 1] = k[i].y; }
-                    host::undistort_points(h->camera, xy.data(), (int)k.size(), xy.data());
-                    for (size_t i = 0; i < k.size(); i++) { k[i].x = xy[2 * i]; k[i].y = xy[2 * i + 1]; }
-                }
-                if (h->has_grid) {
-                    int cnt = (int)k.size();
-                    (void)orbx_assign_grid(&h->grid, k.data(), &cnt, h->h_cell_start.p + (size_t)f * (ncell + 1),
-                                           h->h_cell_items.p + (size_t)f * capacity);
-                    k.resize(cnt);
-                }
-                // cv::ORB::compute drops keypoints whose rounded position is within the border (it may, after
-                // undistortion); the grid built above then refers to the unfiltered list, as in the reference.
-            }
-        };
-        int nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-        nthreads = std::min(nthreads, n_frames);
-        std::vector<std::thread> th;
-        int per = div_up(n_frames, nthreads);
-        for (int t = 0; t < nthreads; t++) {
-            int f0 = t * per, f1 = std::min(n_frames, f0 + per);
-            if (f0 < f1) th.emplace_back(work, f0, f1);
-        }
-        for (auto& t : th) t.join();
-    }
-    h->kp_cap = capacity;
-    ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
-    ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
-    ORBX_TRY(h->d_kp_counts.ensure(n_frames));
-    ORBX_TRY(h->h_kp.ensure((size_t)capacity * n_frames));
-    int* h_counts = h->h_ints.p;
-    for (int f = 0; f < n_frames; f++) {
-        // cv::ORB::compute: runByImageBorder on the (possibly moved) keypoints; octaves are already ascending
-        const size_t pre = sel[f].size();
-        if (h->has_camera) host::run_by_image_border(sel[f], width, height, h->prm.edge_threshold);
-        h_counts[f] = (int)sel[f].size();
-        std::copy(sel[f].begin(), sel[f].end(), h->h_kp.p + (size_t)f * capacity);
-        // grid entries of the dropped keypoints name the slots past the new end: a feature no window accepts
-        for (size_t i = sel[f].size(); i < pre; i++)
-            h->h_kp.p[(size_t)f * capacity + i] = orbx_keypoint{0.f, 0.f, 0.f, -1.f, 0.f, -128, -1};
-    }
-    ORBX_HIP(hipMemcpyAsync(h->d_kp.p, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
-                            hipMemcpyHostToDevice, h->stream));
-    ORBX_HIP(hipMemcpyAsync(h->d_kp_counts.p, h_counts, sizeof(int) * n_frames, hipMemcpyHostToDevice, h->stream));
-    if (h->has_grid) {
-        ORBX_TRY(h->d_cell_start.ensure((size_t)(ncell + 1) * n_frames));
-        ORBX_TRY(h->d_cell_items.ensure((size_t)capacity * n_frames));
-        ORBX_HIP(hipMemcpyAsync(h->d_cell_start.p, h->h_cell_start.p, sizeof(int32_t) * (size_t)(ncell + 1) * n_frames,
-                                hipMemcpyHostToDevice, h->stream));
-        ORBX_HIP(hipMemcpyAsync(h->d_cell_items.p, h->h_cell_items.p, sizeof(int32_t) * (size_t)capacity * n_frames,
-                                hipMemcpyHostToDevice, h->stream));
-    }
-    ORBX_TRY(run_describe_stage(h, n_frames));
-    if (descriptors)
-        ORBX_HIP(hipMemcpyAsync(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost,
-                                h->stream));
-    ORBX_HIP(hipStreamSynchronize(h->stream));
+    ORBX_HIP(hipSetDevice(h->device));
+    const orbx_extractor::Pending a = h->pending;
+    h->pending.active = false;
+    ORBX_HIP(hipEventSynchronize(h->ev_done));
     collect_timings(h);
-    if (counts) std::memcpy(counts, h_counts, sizeof(int) * n_frames);
-    if (keypoints) std::memcpy(keypoints, h->h_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames);
-    return ORBX_OK;
+    const int* h_status = h->h_ints.p;
+    const int* h_cnt = h->h_ints.p + a.n_frames;
+    bool redo = false;
+    for (int f = 0; f < a.n_frames; f++) {
+        if (h_status[f] == 1) return ORBX_CAPACITY;
+        if (h_status[f] == 2) redo = true;
+    }
+    if (!redo) {
+        h->last_counts.assign(h_cnt, h_cnt + a.n_frames);
+        if (counts) std::memcpy(counts, h_cnt, sizeof(int) * a.n_frames);
+        return ORBX_OK;
+    }
+    // a frame had more candidates than the device selection holds: the batch is finished by the host path, and
+    // whatever consumed the device results in the meantime has to run again
+    if (redone) *redone = 1;
+    BlurForkGuard fork_guard{h};
+    return batch_host_path(h, a.n_frames, a.width, a.height, a.capacity, nullptr, counts, nullptr);
 }
 
 orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera* camera, const orbx_grid* grid) {
@@ -1004,6 +1151,13 @@ orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera*
     h->has_grid = grid != nullptr;
     if (camera) h->camera = *camera;
     if (grid) h->grid = *grid;
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled) {
+    if (!h) return ORBX_BAD_ARG;
+    h->image_cache_enabled = enabled != 0;
+    h->cached_image.valid = false;
     return ORBX_OK;
 }
 

@@ -31,7 +31,8 @@ SYMBOLS = [
     "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
-    "orbx_probe_issue_rate", "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+    "orbx_probe_issue_rate", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
+    "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
 
@@ -208,14 +209,26 @@ class Extractor:
         return k[:n.value].copy(), desc[:n.value].copy()
 
     def extract_batch(self, d_images_ptr, n_frames, frame_stride, width, height, stride, channels, capacity,
-                      to_host=True):
+                      to_host=True, deferred=False):
+        """deferred (with to_host=False): return with the work queued; call finish() for the counts and status."""
         kps = np.zeros((n_frames, capacity), KP_DTYPE) if to_host else None
-        counts = np.zeros(n_frames, np.int32)
+        counts = None if (deferred and not to_host) else np.zeros(n_frames, np.int32)
         desc = np.zeros((n_frames, capacity, 32), np.uint8) if to_host else None
+        self._batch_frames = n_frames
         _check(lib().orbx_extract_batch(self._h, C.c_void_p(d_images_ptr), n_frames, C.c_size_t(frame_stride), width,
                                         height, stride, channels, _p(kps), capacity, _p(counts), _p(desc)),
                "orbx_extract_batch")
         return kps, counts, desc
+
+    def finish(self):
+        """orbx_extractor_finish -> (counts, redone)."""
+        counts = np.zeros(getattr(self, "_batch_frames", 1), np.int32)
+        redone = C.c_int(0)
+        _check(lib().orbx_extractor_finish(self._h, _p(counts), C.byref(redone)), "orbx_extractor_finish")
+        return counts, bool(redone.value)
+
+    def set_image_cache(self, enabled):
+        _check(lib().orbx_extractor_set_image_cache(self._h, int(enabled)), "orbx_extractor_set_image_cache")
 
     def set_frame_model(self, camera=None, grid=None):
         _check(lib().orbx_extractor_set_frame_model(self._h, C.byref(camera) if camera is not None else None,

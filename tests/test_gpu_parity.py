@@ -137,6 +137,87 @@ def test_detect_edge_cases(oracle, ex1000):
     ex.close()
 
 
+def test_compute_reuses_the_pyramid_of_detect(oracle, test_images):
+    """detect() then compute() on the same image (MonoFrame::extractFeatures): the second call reuses the uploaded
+    image and its pyramid.  Same results as with the reuse switched off; a different image behind the same buffer
+    address, or one edited in place, is noticed; and the stage timings show that the reusing compute built no pyramid."""
+    p = oracle.orb_params(nfeatures=1000)
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480)
+    buf = np.ascontiguousarray(test_images[0]).copy()
+    want = {}
+    for i, img in enumerate(test_images):
+        ok = oracle.detect(p, img)
+        want[i] = (ok,) + oracle.compute(p, img, ok)
+    for cache in (False, True, True):
+        ex.set_image_cache(cache)
+        buf[...] = test_images[0]
+        k = ex.detect(buf)
+        k2, d = ex.compute(buf, k)
+        t = ex.last_timings()
+        assert (t["gray"] == 0 and t["resize"] == 0) == cache       # no pyramid kernels ran in the reusing compute
+        assert np.array_equal(k, want[0][0].astype(orbx.KP_DTYPE)) and np.array_equal(d, want[0][2])
+        k3, d3 = ex.compute(buf, k)                                 # compute twice in a row
+        assert np.array_equal(d3, want[0][2])
+        # the other image written into the SAME buffer between detect and compute: compute must describe what it is given
+        buf[...] = test_images[1]
+        k4, d4 = ex.compute(buf, want[1][0].astype(orbx.KP_DTYPE))
+        assert np.array_equal(k4, want[1][1].astype(orbx.KP_DTYPE)) and np.array_equal(d4, want[1][2])
+        # an edit in place that touches a sampled row (row 0 is always sampled)
+        k = ex.detect(buf)
+        buf[0:40, 100:300] = 255 - buf[0:40, 100:300]
+        ok = oracle.detect(p, buf)
+        wk, wd = oracle.compute(p, buf, ok)
+        k5, d5 = ex.compute(buf, ok.astype(orbx.KP_DTYPE))
+        assert np.array_equal(d5, wd)
+    ex.close()
+
+
+def test_deferred_batch_and_finish(oracle, test_images):
+    """orbx_extract_batch without host outputs returns with the work queued; orbx_extractor_finish reports the counts
+    and the status.  Same device results as the synchronous call; a frame with more candidates than the on-device
+    selection holds is finished by the host path inside finish() and flagged; too small a capacity is reported there."""
+    import torch
+    w, h = 640, 480
+    rng = np.random.default_rng(17)
+    dense = rng.integers(0, 16, (h, w)).astype(np.uint8)
+    for b in range(h // 3):                           # ~20000 corners on one level: beyond the selection kernel's LDS;
+        n = len(dense[3 * b, (2 * b) % 4::4])         # random heights, so that scores and responses rarely tie
+        dense[3 * b, (2 * b) % 4::4] = rng.integers(120, 256, n)
+    gray = [np.ascontiguousarray(test_images[0][:, :, 1]), np.ascontiguousarray(test_images[1][:, :, 1])]
+    p = oracle.orb_params(nfeatures=1000, nlevels=1)
+    for frames, expect_redo in ((gray, False), ([gray[0], dense], True)):
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        torch.cuda.synchronize()
+        ex = orbx.Extractor(n_key_points=1000, level_pyramid=1, max_width=w, max_height=h, max_batch=2)
+        cap = 1280
+        ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, cap, to_host=False, deferred=True)
+        counts, redone = ex.finish()
+        assert redone == expect_redo
+        kp_ptr, desc_ptr, cnt_ptr, kcap = ex.device_results()
+        kp = torch.as_tensor(_DevView(kp_ptr, (2, kcap, 7), "<f4"), device="cuda").cpu().numpy().view(np.uint8)
+        kp = np.ascontiguousarray(kp).view(orbx.KP_DTYPE).reshape(2, kcap)
+        desc = torch.as_tensor(_DevView(desc_ptr, (2, kcap, 32), "|u1"), device="cuda").cpu().numpy()
+        dcnt = torch.as_tensor(_DevView(cnt_ptr, (2,), "<i4"), device="cuda").cpu().numpy()
+        assert np.array_equal(dcnt, counts)
+        for f, img in enumerate(frames):
+            ok_, od = oracle.compute(p, img, oracle.detect(p, img))
+            assert counts[f] == len(ok_)
+            assert np.array_equal(kp[f, :counts[f]], ok_.astype(orbx.KP_DTYPE)) and np.array_equal(desc[f, :counts[f]], od)
+        # finish() without an outstanding batch hands the same counts over again
+        again, redone2 = ex.finish()
+        assert np.array_equal(again, counts) and not redone2
+        # capacity too small: reported by finish(), not by the call that queued the work
+        ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, 300, to_host=False, deferred=True)
+        with pytest.raises(orbx.OrbxError) as e:
+            ex.finish()
+        assert e.value.status == orbx.CAPACITY
+        # a deferred batch that is never finished is dropped by the next call
+        ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, cap, to_host=False, deferred=True)
+        kps, c2, d2 = ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, cap)
+        assert np.array_equal(c2, counts)
+        ex.close()
+
+
 def test_more_corners_than_the_candidate_list_holds(oracle):
     """cv::ORB has no limit on the number of FAST corners; the candidate list here starts at one per 16 pyramid pixels
     and must grow when a frame has more.  Bright dots on the lattice spanned by (4, 0) and (2, 3) put no lattice point
@@ -333,9 +414,11 @@ def test_match_hamming_batch_ragged_pairs(oracle, matcher):
     counts = torch.tensor([255, 256, 257, 511, 512, 513], dtype=torch.int32)
     db_desc, db_counts = kfdb.gather_database(desc, counts, [0, 2, 3, 5])
     want_i, want_d = kfdb.match_frames_against_database(kfdb.NumpyBackend(), desc, counts, db_desc, db_counts)
-    matcher.set_stream(torch.cuda.current_stream().cuda_stream)
-    got_i, got_d = kfdb.match_frames_against_database(kfdb.HipBackend(matcher), desc.cuda(), counts.cuda(),
-                                                      db_desc.cuda(), db_counts.cuda())
+    ts = torch.cuda.Stream()   # torch's default stream has handle 0, which set_stream reads as "the handle's own"
+    with torch.cuda.stream(ts):
+        matcher.set_stream(ts.cuda_stream)
+        got_i, got_d = kfdb.match_frames_against_database(kfdb.HipBackend(matcher), desc.cuda(), counts.cuda(),
+                                                          db_desc.cuda(), db_counts.cuda())
     torch.cuda.synchronize()
     matcher.set_stream(0)
     for f in range(6):
