@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--kfdb-frames", type=int, default=1250,
                     help="frames per GPU of the key-frame database leg (0 = skip): every 10th is a key frame, the "
                          "ranks all-gather their key frames' descriptors and match every frame against all of them")
+    ap.add_argument("--frames-4k", type=int, default=32,
+                    help="frames per GPU of the 4K extraction leg (3840x2160 gray, 8000 kp, 12 levels; 0 = skip)")
     ap.add_argument("--profile-round", default="r02", help="prefix of the PMC summaries under profiles/ to quote")
     args = ap.parse_args()
 
@@ -492,6 +494,53 @@ def main():
                                      "grows with the number of GPUs"}
         del kframes, exk
 
+    # ---- 4K extraction leg (BASELINE config 4): 3840x2160 gray, 8000 keypoints, 12 levels, extraction only -------------
+    line_4k = None
+    if args.frames_4k > 0:
+        W4, H4, B4, CAP4, L4 = 3840, 2160, args.frames_4k, 9000, 12
+        g4 = torch.Generator(device=device)
+        g4.manual_seed(4 + rank)
+        distinct = []
+        for _ in range(min(4, B4)):   # rectangles of random gray on a flat ground + noise: corners at every scale
+            img = torch.full((H4, W4), 100.0, device=device)
+            geo = torch.randint(0, 1 << 30, (6000, 5), generator=g4, device=device).cpu().numpy()
+            for x0, y0, ww, hh, v in geo:
+                x0, y0, ww, hh = int(x0 % W4), int(y0 % H4), int(3 + ww % 397), int(3 + hh % 297)
+                img[y0:y0 + hh, x0:x0 + ww] = float(v % 256)
+            img = img + torch.randn((H4, W4), generator=g4, device=device) * 2.5
+            distinct.append(img.clamp(0, 255).round().to(torch.uint8))
+        f4 = torch.stack([distinct[i % len(distinct)] for i in range(B4)]).contiguous()
+        ex4 = orbx.Extractor(n_key_points=8000, level_pyramid=L4, max_width=W4, max_height=H4, max_batch=B4,
+                             device=local_rank)
+        ex4.set_stream(stream)
+
+        def step4():
+            ex4.extract_batch(f4.data_ptr(), B4, W4 * H4, W4, H4, W4, 1, CAP4, to_host=False, deferred=True)
+            torch.cuda.synchronize()
+            return ex4.finish()
+        step4()
+        barrier()
+        q0 = time.perf_counter()
+        reps4 = 3
+        for _ in range(reps4):
+            cnt4, redone4 = step4()
+        barrier()
+        dt4 = (time.perf_counter() - q0) / reps4
+        if world > 1:
+            t = torch.tensor([dt4], dtype=torch.float64, device=red_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt4 = float(t.item())
+        lv4 = [(int(round(W4 / 1.2 ** l)), int(round(H4 / 1.2 ** l))) for l in range(L4)]
+        P4 = sum(a * b for a, b in lv4)
+        bytes4 = W4 * H4 + 4 * P4 + 8000 * (2 * 81 + 709 + 512)   # gray input: read once, pyramid written and read twice
+        line_4k = {"workload": "3840x2160 gray, 8000 kp, 12 levels x1.2, detect + compute, frames resident in HBM",
+                   "frames_per_gpu_per_batch": B4, "frames_per_s": world * B4 / dt4, "ms_per_batch": dt4 * 1e3,
+                   "mean_keypoints": float(np.mean(cnt4)), "selection_on_device": not redone4,
+                   "algorithmic_bytes_per_frame": bytes4,
+                   "achieved_GBps": bytes4 * B4 / dt4 / 1e9, "frac_of_8TBps": bytes4 * B4 / dt4 / 8e12,
+                   "stage_ms_per_batch": ex4.last_timings()}
+        del f4, ex4, distinct
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # up to the whole batch, cut off after about 12 s of CPU work
@@ -510,7 +559,7 @@ def main():
                        "mean_window_matches": mean_matches,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roofline, "roofline_ransac": roofline_ransac, "roofline_match": roofline_match,
-            "ransac": ransac, "extra": {"key_frame_database": kfdb_line, "issue_rate_probe_lane_ops_per_s": probe},
+            "ransac": ransac, "extra": {"key_frame_database": kfdb_line, "extraction_4k": line_4k, "issue_rate_probe_lane_ops_per_s": probe},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

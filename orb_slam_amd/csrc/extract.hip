@@ -84,6 +84,7 @@ struct orbx_extractor {
     DevBuf<int32_t> d_cell_start, d_cell_items;
     PinBuf<int32_t> h_cell_start, h_cell_items;
     DevBuf<int> d_status;
+    DevBuf<unsigned char> d_select_ws;  // workspace of the selection kernel's global form
     bool device_select = true;     // batch path: select / undistort / grid on the device (k_select_frame)
     bool select_attr_set = false;
     size_t select_attr_bytes = 0;
@@ -725,6 +726,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();
     h->d_cell_start.release(); h->d_cell_items.release(); h->h_cell_start.release(); h->h_cell_items.release();
     h->d_status.release();
+    h->d_select_ws.release();
     h->timer.destroy();
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
     if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
@@ -1006,14 +1008,17 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, true));
 
     // Device-resident path: selection, undistortion, bucket grid and border filter run in one kernel per frame
-    // (k_select_frame), so nothing crosses PCIe between detect and compute.  It covers frames whose candidates fit
-    // its LDS; otherwise (status 2) the whole batch is redone by the host path below, which has no such limit.
+    // (k_select_frame), so nothing crosses PCIe between detect and compute.  Its fast form keeps a frame's candidates
+    // and keypoint slots in LDS; frames beyond that (more than kSelectMaxCands candidates, or a keypoint capacity
+    // that does not fit beside them: 4K frames, thousands of keypoints) take the same kernel on a global workspace.
+    // Only a frame with more candidates than the candidate list holds is left to the host path (which enlarges it).
     const int ncell_dev = h->has_grid ? h->grid.grid_cols * h->grid.grid_rows : 0;
-    // the device path needs its selection elements and `capacity` keypoint slots in one CU's LDS (160 KB)
+    // the LDS form needs its selection elements and `capacity` keypoint slots in one CU's LDS (160 KB)
     const size_t select_lds_full = sizeof(stdsel::Elem) * (size_t)kSelectMaxCands +
                                    std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)),
                                             sizeof(uint16_t) * 2 * (size_t)kSelectMaxCands);
-    if (h->device_select && select_lds_full <= 160 * 1024 - 512 && ncell_dev + 1 <= kSelectMaxCands * 2) {
+    const bool lds_form = select_lds_full <= 160 * 1024 - 512 && ncell_dev + 1 <= kSelectMaxCands * 2;
+    if (h->device_select && h->geom.nlevels <= 16) {
         h->kp_cap = capacity;
         ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
         ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
@@ -1041,28 +1046,51 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
             return sizeof(stdsel::Elem) * (size_t)max_cands +
                    std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)), sizeof(uint16_t) * 2 * (size_t)max_cands);
         };
-        const size_t shmem = select_lds(kSelectMaxCands);
-        if (!h->select_attr_set || shmem > h->select_attr_bytes) {
-            ORBX_HIP(hipFuncSetAttribute((const void*)k_select_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            h->select_attr_set = true;
-            h->select_attr_bytes = shmem;
-        }
-        const long half_cu = 80 * 1024 - 512;  // half of the CU's 160 KB, less the kernel's static LDS and rounding
-        const long kp_area = (long)capacity * (long)(sizeof(orbx_keypoint) + sizeof(int));
-        const int small_cands = (int)((half_cu - kp_area) / (long)sizeof(stdsel::Elem)) / 64 * 64;
-        const bool two_tier = small_cands >= 2048 && small_cands < kSelectMaxCands && ncell_dev + 1 <= small_cands * 2;
+        // the global form's workspace: per slice the selection elements of cand_cap candidates, then the keypoint /
+        // cell area or the (32-bit) stopper lists, whichever is larger.  With the LDS form in front only the rare
+        // frame needs a slice (a few are kept; a batch with more such frames than slices goes to the host path).
+        const int ws_slices = lds_form ? std::min(n_frames, 8) : n_frames;
+        const size_t ws_stride = (sizeof(stdsel::Elem) * (size_t)h->cand_cap +
+                                  std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)),
+                                           sizeof(uint32_t) * 2 * (size_t)h->cand_cap) + 255) & ~(size_t)255;
+        ORBX_TRY(h->d_select_ws.ensure(ws_stride * ws_slices + sizeof(int) * 64));
+        int* ws_counter = (int*)(h->d_select_ws.p + ws_stride * ws_slices);
+        ORBX_HIP(hipMemsetAsync(ws_counter, 0, sizeof(int), h->stream));
         h->timer.begin(ST_SELECT, h->stream);
-        auto launch_select = [&](int max_cands, int pass) {
-            hipLaunchKernelGGL(k_select_frame, dim3(n_frames), dim3(64 * h->geom.nlevels), select_lds(max_cands),
-                               h->stream, h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm,
-                               h->d_kp.p, capacity, h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p,
-                               h->d_status.p, max_cands, pass);
+        auto launch_global = [&](int pass) {
+            hipLaunchKernelGGL(k_select_frame<true>, dim3(n_frames), dim3(64 * h->geom.nlevels), 0, h->stream,
+                               h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm, h->d_kp.p,
+                               capacity, h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p,
+                               h->cand_cap, pass, h->d_select_ws.p, ws_stride, ws_slices, ws_counter);
         };
-        if (two_tier) {
-            launch_select(small_cands, 0);
-            launch_select(kSelectMaxCands, 1);
+        if (lds_form) {
+            const size_t shmem = select_lds(kSelectMaxCands);
+            if (!h->select_attr_set || shmem > h->select_attr_bytes) {
+                ORBX_HIP(hipFuncSetAttribute((const void*)k_select_frame<false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                h->select_attr_set = true;
+                h->select_attr_bytes = shmem;
+            }
+            const long half_cu = 80 * 1024 - 512;  // half of the CU's 160 KB, less the kernel's static LDS and rounding
+            const long kp_area = (long)capacity * (long)(sizeof(orbx_keypoint) + sizeof(int));
+            const int small_cands = (int)((half_cu - kp_area) / (long)sizeof(stdsel::Elem)) / 64 * 64;
+            const bool two_tier = small_cands >= 2048 && small_cands < kSelectMaxCands && ncell_dev + 1 <= small_cands * 2;
+            auto launch_select = [&](int max_cands, int pass) {
+                hipLaunchKernelGGL(k_select_frame<false>, dim3(n_frames), dim3(64 * h->geom.nlevels),
+                                   select_lds(max_cands), h->stream, h->d_cand.p, h->cand_cap, h->d_level_counts_p,
+                                   h->d_totals.p, h->geom, fm, h->d_kp.p, capacity, h->d_kp_counts.p,
+                                   h->d_cell_start.p, h->d_cell_items.p, h->d_status.p, max_cands, pass, nullptr, 0, 0,
+                                   nullptr);
+            };
+            if (two_tier) {
+                launch_select(small_cands, 0);
+                launch_select(kSelectMaxCands, 1);
+            } else {
+                launch_select(kSelectMaxCands, -1);
+            }
+            launch_global(2);  // frames the LDS form could not hold
         } else {
-            launch_select(kSelectMaxCands, -1);
+            launch_global(-1);
         }
         h->timer.end(ST_SELECT, h->stream);
         ORBX_HIP(hipGetLastError());

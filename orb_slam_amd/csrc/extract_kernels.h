@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "extract_types.h"
 #include "orbx.h"
 #include "stdsel.h"
@@ -970,29 +972,48 @@ __device__ __forceinline__ int compact_ordered(orbx_keypoint* s_kp, int n, int l
 //   Camera::undistortPoints, Frame::assignFeaturesToGrid (ordered filter + CSR cells), and the border filter of
 //   cv::ORB::compute.  status[frame]: 0 ok, 1 more keypoints than kp_cap, 2 more candidates than the LDS holds
 //   (3 between the two launches: left to the full-size one).
+// GLOBAL = false: the working arrays live in the workgroup's LDS (max_cands candidates, kp_cap keypoint slots must
+// fit it).  GLOBAL = true: the same code on a per-frame slice of a global workspace, for frames beyond that (4K
+// frames, thousands of keypoints): slower per frame, but nothing crosses PCIe and nothing has a fixed limit; pass 2
+// of that form takes only the frames an LDS launch marked with status 2.
+template <bool GLOBAL>
 __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ cand, int cand_cap,
                                                         const int* __restrict__ level_counts,
                                                         const int* __restrict__ totals, Geom g, FrameModel fm,
                                                         orbx_keypoint* __restrict__ kps_out, int kp_cap,
                                                         int* __restrict__ kp_counts, int* __restrict__ cell_start,
                                                         int* __restrict__ cell_items, int* __restrict__ status,
-                                                        int max_cands, int pass) {
-    extern __shared__ __align__(16) unsigned char s_raw[];
-    __shared__ int s_n[kMaxLevels], s_off[kMaxLevels], s_cnt;
+                                                        int max_cands, int pass, unsigned char* __restrict__ ws,
+                                                        size_t ws_stride, int ws_slices,
+                                                        int* __restrict__ ws_counter) {
+    extern __shared__ __align__(16) unsigned char s_lds[];
+    __shared__ int s_n[kMaxLevels], s_off[kMaxLevels], s_cnt, s_slice;
+    typedef typename std::conditional<GLOBAL, uint32_t, uint16_t>::type St;
+    const int b = blockIdx.x;
+    if (pass == 1 && status[b] != 3) return;
+    if (pass == 2 && status[b] != 2) return;
+    int slice = b;
+    if (GLOBAL && pass == 2) {
+        // frames arrive here rarely: they share a few workspace slices, handed out in arrival order
+        if (totals[b] > cand_cap) return;  // the candidate list itself overflowed: the host path enlarges it
+        if (threadIdx.x == 0) s_slice = atomicAdd(ws_counter, 1);
+        __syncthreads();
+        slice = s_slice;
+        if (slice >= ws_slices) return;    // status stays 2
+    }
+    unsigned char* s_raw = GLOBAL ? ws + (size_t)slice * ws_stride : s_lds;
     stdsel::Elem* s_el = (stdsel::Elem*)s_raw;                                  // [max_cands]
     orbx_keypoint* s_kp = (orbx_keypoint*)(s_raw + sizeof(stdsel::Elem) * max_cands);  // [kp_cap]
     int* s_cell = (int*)(s_kp + kp_cap);                                         // [kp_cap]
     int* s_cells = (int*)s_raw;                                                  // [ncell + 1], aliases s_el later
     // stopper lists of the wave-parallel partitions; they alias s_kp / s_cell, which are idle during the selection
-    uint16_t* s_lp = (uint16_t*)s_kp;                                            // [max_cands]
-    uint16_t* s_rp = s_lp + max_cands;                                           // [max_cands]
-    const int b = blockIdx.x;
+    St* s_lp = (St*)s_kp;                                                        // [max_cands]
+    St* s_rp = s_lp + max_cands;                                                 // [max_cands]
     const int tid = threadIdx.x, lane = tid & 63, lvl = tid >> 6;
     const Cand* cd = cand + (size_t)b * cand_cap;
     const int total = totals[b];
     // pass 0: the launch with the small LDS leaves frames that do not fit it to pass 1 (status 3); pass 1 takes only
-    // those; pass -1 is the single full-size launch
-    if (pass == 1 && status[b] != 3) return;
+    // those; pass -1 is a single launch for every frame; pass 2 (global form) takes the frames an LDS launch left
     if (total > max_cands || total > cand_cap) {
         if (tid == 0) { status[b] = (pass == 0 && total <= cand_cap) ? 3 : 2; kp_counts[b] = 0; }
         return;

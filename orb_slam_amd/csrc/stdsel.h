@@ -199,16 +199,19 @@ ORBX_HD inline int retain_best(Elem* a, int n, int n_points) {
 // (they touch a handful of elements, or never run on real data).  a, lp and rp are LDS arrays; every lane of the
 // wavefront must call with the same arguments.
 
+// (workgroup scope: the arrays may live in global memory, where the lanes' stores must have left the wavefront
+// before other lanes load them; for LDS arrays this costs the same as the wavefront-scope form)
 __device__ inline void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // MODE 0: std::__unguarded_partition(lo, hi, pivot) for KeypointResponseGreater, pivot key p; returns the cut.
 // MODE 1: std::partition(lo, hi, key >= p), bidirectional form; returns the partition point.
-template <int MODE>
-__device__ inline int wave_partition(Elem* a, int lo, int hi, float p, uint16_t* lp, uint16_t* rp, int lane) {
+// St: type of the stopper entries (offsets from lo): uint16_t while a range has fewer than 65536 elements.
+template <int MODE, typename St>
+__device__ inline int wave_partition(Elem* a, int lo, int hi, float p, St* lp, St* rp, int lane) {
     int nL = 0, nR = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int base = lo; base < hi; base += 64) {
@@ -218,8 +221,8 @@ __device__ inline int wave_partition(Elem* a, int lo, int hi, float p, uint16_t*
         const bool is_l = in && (MODE == 0 ? !(k > p) : !(k >= p));
         const bool is_r = in && (MODE == 0 ? !(p > k) : (k >= p));
         const unsigned long long bl = __ballot(is_l), br = __ballot(is_r);
-        if (is_l) lp[nL + __popcll(bl & below)] = (uint16_t)(i - lo);
-        if (is_r) rp[nR + __popcll(br & below)] = (uint16_t)(i - lo);
+        if (is_l) lp[nL + __popcll(bl & below)] = (St)(i - lo);
+        if (is_r) rp[nR + __popcll(br & below)] = (St)(i - lo);
         nL += __popcll(bl);
         nR += __popcll(br);
     }
@@ -255,7 +258,8 @@ __device__ inline int wave_partition(Elem* a, int lo, int hi, float p, uint16_t*
     return cut;
 }
 
-__device__ inline void wave_nth_element(Elem* a, int first, int nth, int last, uint16_t* lp, uint16_t* rp, int lane) {
+template <typename St>
+__device__ inline void wave_nth_element(Elem* a, int first, int nth, int last, St* lp, St* rp, int lane) {
     if (first == last || nth == last) return;
     int depth_limit = lg(last - first) * 2;
     while (last - first > 3) {
@@ -271,7 +275,7 @@ __device__ inline void wave_nth_element(Elem* a, int first, int nth, int last, u
         if (lane == 0) move_median_to_first(a + first, a + first + 1, a + first + (last - first) / 2, a + last - 1);
         wave_sync();
         const float pivot = a[first].key;
-        const int cut = wave_partition<0>(a, first + 1, last, pivot, lp, rp, lane);
+        const int cut = wave_partition<0, St>(a, first + 1, last, pivot, lp, rp, lane);
         if (cut <= nth) first = cut;
         else last = cut;
     }
@@ -279,13 +283,14 @@ __device__ inline void wave_nth_element(Elem* a, int first, int nth, int last, u
     wave_sync();
 }
 
-// cv::KeyPointsFilter::retainBest by one wavefront; lp / rp hold n 16-bit entries each.  Returns the new length.
-__device__ inline int wave_retain_best(Elem* a, int n, int n_points, uint16_t* lp, uint16_t* rp, int lane) {
+// cv::KeyPointsFilter::retainBest by one wavefront; lp / rp hold n entries each.  Returns the new length.
+template <typename St>
+__device__ inline int wave_retain_best(Elem* a, int n, int n_points, St* lp, St* rp, int lane) {
     if (n_points >= 0 && n > n_points) {
         if (n_points == 0) return 0;
         wave_nth_element(a, 0, n_points - 1, n, lp, rp, lane);
         const float ambiguous = a[n_points - 1].key;
-        return wave_partition<1>(a, n_points, n, ambiguous, lp, rp, lane);
+        return wave_partition<1, St>(a, n_points, n, ambiguous, lp, rp, lane);
     }
     return n;
 }

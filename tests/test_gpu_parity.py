@@ -320,6 +320,35 @@ def test_selection_launch_tiers(oracle, test_images):
     ex.close()
 
 
+def test_selection_of_a_frame_beyond_the_lds_form(oracle, test_images):
+    """A VGA frame of pure noise has several times the 8192 candidates the selection kernel keeps in LDS: inside a
+    batch it is selected by the kernel's global-memory form, on the device (no hand-over to the host selection),
+    while its neighbours take the LDS form; all equal the oracle."""
+    import torch
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (480, 640, 3)).astype(np.uint8)
+    frames = [test_images[0], noise, test_images[1], np.ascontiguousarray(noise[::-1])]
+    p = oracle.orb_params(nfeatures=1000)
+    ora = [oracle.compute(p, img, oracle.detect(p, img)) for img in frames]
+    p_all = oracle.orb_params(nfeatures=200000)
+    assert len(oracle.detect(p_all, noise)) > 2 * 8192
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(frames))
+    for cap in (1280, 2300):
+        ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap, to_host=False,
+                         deferred=True)
+        counts, redone = ex.finish()
+        assert not redone
+        kps, c2, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+        assert np.array_equal(counts, c2)
+        for f, (ok_, od) in enumerate(ora):
+            assert counts[f] == len(ok_), (cap, f)
+            assert np.array_equal(kps[f, :counts[f]], ok_.astype(orbx.KP_DTYPE)), (cap, f)
+            assert np.array_equal(desc[f, :counts[f]], od), (cap, f)
+    ex.close()
+
+
 def test_extract_batch_ragged_inputs(oracle):
     """Odd frame sizes, padded row strides, gray and colour input, and frames with no or almost no corners inside one
     batch: every frame equals the oracle's detect + compute of that frame."""
@@ -815,8 +844,10 @@ def test_wave_parallel_retain_best_matches_libstdcxx(oracle):
 
 
 def test_4k_extraction_bit_exact(oracle):
-    """3840x2160 gray frames, 8000 keypoints, 12 levels: single-frame detect / compute and the batch path (whose
-    device selection does not hold this many candidates and hands over to the host selection) against the oracle."""
+    """3840x2160 gray frames, 8000 keypoints, 12 levels: single-frame detect / compute and the batch path against the
+    oracle.  The batch's selection does not fit the selection kernel's LDS at this size: it runs in the kernel's
+    global-memory form, still on the device (finish() reports no hand-over to the host selection), with and without
+    the frame model; the host selection gives the same."""
     import torch
     w, h = 3840, 2160
     rng = np.random.default_rng(41)
@@ -841,11 +872,36 @@ def test_4k_extraction_bit_exact(oracle):
     assert np.array_equal(k2, ora[0][1].astype(orbx.KP_DTYPE)) and np.array_equal(d2, ora[0][2])
     dev = torch.from_numpy(np.stack(frames)).cuda()
     torch.cuda.synchronize()
-    kps, counts, desc = ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, 9000)
+    for device_select in (True, False):
+        ex.set_device_select(device_select)
+        kps, counts, desc = ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, 9000)
+        for f in range(2):
+            assert counts[f] == len(ora[f][1])
+            assert np.array_equal(kps[f, :counts[f]], ora[f][1].astype(orbx.KP_DTYPE))
+            assert np.array_equal(desc[f, :counts[f]], ora[f][2])
+    ex.set_device_select(True)
+    ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, 9000, to_host=False, deferred=True)
+    c2, redone = ex.finish()
+    assert not redone and np.array_equal(c2, counts)            # completed on the device
+    # with the frame model (undistortion, 64 x 64 grid, border filter) at this size, device against host selection
+    cam = orbx.make_camera(2800.0, 2800.0, 1919.5, 1079.5, [-0.05, 0.01, 0.0005, -0.0005, 0.0])
+    grid = orbx.make_grid((0.0, float(w), 0.0, float(h)))
+    ex.set_frame_model(cam, grid)
+    res = []
+    for device_select in (True, False):
+        ex.set_device_select(device_select)
+        kps, counts, desc = ex.extract_batch(dev.data_ptr(), 2, w * h, w, h, w, 1, 9000)
+        cs, ci = ex.device_grid()
+        ncell = grid.grid_cols * grid.grid_rows
+        starts = torch.as_tensor(_DevView(cs, (2, ncell + 1), "<i4"), device="cuda").cpu().numpy().copy()
+        items = torch.as_tensor(_DevView(ci, (2, 9000), "<i4"), device="cuda").cpu().numpy().copy()
+        res.append((kps.copy(), counts.copy(), desc.copy(), starts, items))
+    a, b = res
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]) and a[1].min() > 7000
     for f in range(2):
-        assert counts[f] == len(ora[f][1])
-        assert np.array_equal(kps[f, :counts[f]], ora[f][1].astype(orbx.KP_DTYPE))
-        assert np.array_equal(desc[f, :counts[f]], ora[f][2])
+        n, nk = a[1][f], a[3][f, -1]
+        assert np.array_equal(a[0][f, :n], b[0][f, :n]) and np.array_equal(a[2][f, :n], b[2][f, :n])
+        assert np.array_equal(a[4][f, :nk], b[4][f, :nk])
     ex.close()
 
 
