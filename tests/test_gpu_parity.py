@@ -1163,6 +1163,75 @@ def test_full_size_batches_are_consistent(oracle, ransac, test_images):
         assert (kps[f_all, :len(ok_)] == ok_.astype(orbx.KP_DTYPE)[None]).all()
         assert (desc[f_all, :len(ok_)] == od[None]).all()
     ex.close()
+    # the bench's own configuration: frame model on (TUM lens, 64 x 64 grid), selection on the device, and the windowed
+    # match of all 791 consecutive pairs (radius 15, orientation check): every pair equals the oracle's result for
+    # its kind (the frames repeat with period 4, so there are four kinds of pair)
+    cam = orbx.make_camera(517.3, 516.5, 318.6, 255.3, TUM_DIST)
+    ocam = oracle.camera(517.3, 516.5, 318.6, 255.3, TUM_DIST, 640, 480)
+    bounds = oracle.image_bounds(ocam)
+    grid, og = orbx.make_grid(bounds), oracle.grid_params(bounds)
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=B)
+    ex.set_frame_model(cam, grid)
+    mt = orbx.Matcher()
+    ts = torch.cuda.Stream()
+    ex.set_stream(ts.cuda_stream)
+    mt.set_stream(ts.cuda_stream)
+    distinct = [test_images[0], np.roll(test_images[0], 3, axis=1).copy(), test_images[1],
+                np.roll(test_images[1], -2, axis=0).copy()]           # neighbours show (nearly) the same scene
+    del dev
+    dev = torch.from_numpy(np.stack([distinct[f % 4] for f in range(B)])).cuda()
+    torch.cuda.synchronize()
+    ora = []
+    for img in distinct:
+        k = oracle.detect(p, img)
+        xy = oracle.undistort_points(ocam, np.stack([k["x"], k["y"]], 1))
+        k["x"], k["y"] = xy[:, 0], xy[:, 1]
+        k, start, items = oracle.assign_grid(og, k)
+        k2, d = oracle.compute(p, img, k)
+        ora.append((k2, d, start, items))
+    rng = np.random.default_rng(97)
+    shift = [rng.normal(0, 3, (cap, 2)).astype(np.float32) for _ in range(4)]   # per kind of pair
+    proj = np.zeros((B - 1, cap, 2), np.float32)
+    for i in range(B - 1):
+        rk = ora[i % 4][0]                                                      # pair i: frame i + 1 against frame i
+        proj[i, :len(rk), 0] = rk["x"] + shift[i % 4][:len(rk), 0]
+        proj[i, :len(rk), 1] = rk["y"] + shift[i % 4][:len(rk), 1]
+    with torch.cuda.stream(ts):
+        d_fi = torch.arange(1, B, dtype=torch.int32, device="cuda")
+        d_ri = torch.arange(0, B - 1, dtype=torch.int32, device="cuda")
+        d_proj = torch.from_numpy(proj).cuda()
+        d_matched = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda")
+        d_dist = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda")
+        d_nm = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
+        ex.extract_batch(dev.data_ptr(), B, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap, to_host=False, deferred=True)
+        kp_ptr, desc_ptr, cnt_ptr, kcap = ex.device_results()
+        cs_ptr, ci_ptr = ex.device_grid()
+        _, sf, _, _, _ = ex.scale_tables()
+        mt.match_projection_frame_batch(grid, B - 1, d_fi.data_ptr(), d_ri.data_ptr(), kp_ptr, desc_ptr, cnt_ptr, cap,
+                                        cs_ptr, ci_ptr, 0, d_proj.data_ptr(), 0, sf, 0, 15.0, True,
+                                        d_matched.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr())
+    torch.cuda.synchronize()
+    counts, redone = ex.finish()
+    assert not redone
+    hm, hd, hn = d_matched.cpu().numpy(), d_dist.cpu().numpy(), d_nm.cpu().numpy()
+    for u in range(4):
+        fk, fd, start, items = ora[(u + 1) % 4]
+        rk, rd = ora[u][0], ora[u][1]
+        assert (counts[np.arange((u + 1) % 4, B, 4)] == len(fk)).all()
+        om = oracle.match_projection_frame(og, start, items, fk, fd, rk, np.ones(len(rk), np.uint8),
+                                           proj[u, :len(rk)], np.ones(len(rk), np.float32), rd, sf, 0, 15.0, True)
+        assert len(om) > 100
+        want_m = np.zeros(cap, np.int32)
+        want_d = np.zeros(cap, np.int32)
+        want_m[om["query"]] = om["train"]
+        want_d[om["query"]] = om["distance"].astype(np.int32)
+        idx = np.arange(u, B - 1, 4)
+        got_m = np.where(hm[idx] > 0, hm[idx], 0)
+        assert (hn[idx] == len(om)).all()
+        assert (got_m == want_m[None]).all()
+        assert (np.where(hm[idx] > 0, hd[idx], 0) == want_d[None]).all()
+    ex.close()
+    mt.close()
     # RANSAC: 1024 pairs tiled from 8 distinct ones
     rng = np.random.default_rng(93)
     P, n, it, D = 1024, 2000, 200, 8
