@@ -300,6 +300,23 @@ orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, co
                                          const uint8_t* point_descriptors, const float* scale_factors, int n_levels,
                                          float radius, float nn_ratio, orbx_match* matches, int* count);
 
+/* Batched form of orbx_match_projection_points on the device results of an extractor: pair p matches the map points
+   of its own list (d_n_points[p] of them; per-pair arrays [pairs][points_capacity]: in_view, proj_xy (x 2),
+   pred_level, view_cos, point descriptors (x 32)) against frame d_frame_index[p] - what Tracker::projectLocalPoints
+   (src/tracker.cpp:606-607 -> orb_matcher.cpp:257-352) does for one frame, for many frames per call.  Outputs as in
+   orbx_match_projection_frame_batch: d_matched / d_distance [pairs][kp_capacity] per frame feature, d_n_matches. */
+orbx_status orbx_match_projection_points_batch(orbx_matcher* h, const orbx_grid* g, int n_pairs,
+                                               const int32_t* d_frame_index, const orbx_keypoint* d_keypoints,
+                                               const uint8_t* d_descriptors, const int32_t* d_counts,
+                                               int kp_capacity, const int32_t* d_cell_start,
+                                               const int32_t* d_cell_items, int points_capacity,
+                                               const int32_t* d_n_points, const uint8_t* d_in_view,
+                                               const float* d_proj_xy, const int32_t* d_pred_level,
+                                               const float* d_view_cos, const uint8_t* d_point_descriptors,
+                                               const float* scale_factors, int n_levels, float radius,
+                                               float nn_ratio, int32_t* d_matched, int32_t* d_distance,
+                                               int32_t* d_n_matches);
+
 /* ------------------------------------------------------------------ two-view RANSAC ------------------------- */
 
 orbx_status orbx_ransac_create(int device, orbx_ransac** out);

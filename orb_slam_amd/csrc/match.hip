@@ -180,6 +180,9 @@ struct ProjArgs {
     size_t kp_stride;            // keypoints (and cell items) per frame slot
     size_t cell_stride;          // cell_start entries per frame slot
     size_t pair_stride;          // entries per pair in the per-pair arrays
+    size_t out_stride;           // entries per pair in matched / dists (0: pair_stride)
+    const int32_t* n_ref_pair;   // reference points per PAIR (map-point mode, batched), or NULL
+    int ref_desc_per_pair;       // reference descriptors are a per-pair array (map points), not a per-frame one
     const int32_t* cell_start;
     const int32_t* cell_items;
     const orbx_keypoint* kps;   // frame features
@@ -250,21 +253,23 @@ __device__ __forceinline__ void resolve_views(ProjArgs& A, int pair) {
     const int fi = A.frame_index ? A.frame_index[pair] : 0;
     const int ri = A.ref_index ? A.ref_index[pair] : 0;
     A.n = A.counts ? A.counts[fi] : A.n;
-    A.n_ref = A.counts ? A.counts[ri] : A.n_ref;
+    A.n_ref = A.n_ref_pair ? A.n_ref_pair[pair] : (A.counts ? A.counts[ri] : A.n_ref);
     A.kps += (size_t)fi * A.kp_stride;
     A.desc += (size_t)fi * A.kp_stride * 32;
     A.cell_start += (size_t)fi * A.cell_stride;
     A.cell_items += (size_t)fi * A.kp_stride;
     if (A.ref_kps) A.ref_kps += (size_t)ri * A.kp_stride;
-    A.ref_desc += (size_t)ri * A.kp_stride * 32;
     const size_t po = (size_t)pair * A.pair_stride;
+    A.ref_desc += A.ref_desc_per_pair ? po * 32 : (size_t)ri * A.kp_stride * 32;
+    A.n_ref = min(A.n_ref, A.pair_stride ? (int)A.pair_stride : A.n_ref);
     if (A.ref_flag) A.ref_flag += po;
     A.proj_xy += po * 2;
     if (A.proj_z) A.proj_z += po;
     if (A.pred_level) A.pred_level += po;
     if (A.view_cos) A.view_cos += po;
-    A.matched += po;
-    A.dists += po;
+    const size_t oo = (size_t)pair * (A.out_stride ? A.out_stride : A.pair_stride);
+    A.matched += oo;
+    A.dists += oo;
     A.pushes += po * 2;
     A.status += pair;
     if (A.n_matches) A.n_matches += pair;
@@ -1903,6 +1908,77 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
         h->fast_lds_attr = fast_lds;
     }
     hipLaunchKernelGGL(k_resolve_sorted, dim3(n_pairs), dim3(64), fast_lds, s, A);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
+orbx_status orbx_match_projection_points_batch(orbx_matcher* h, const orbx_grid* g, int n_pairs,
+                                               const int32_t* d_frame_index, const orbx_keypoint* d_keypoints,
+                                               const uint8_t* d_descriptors, const int32_t* d_counts,
+                                               int kp_capacity, const int32_t* d_cell_start,
+                                               const int32_t* d_cell_items, int points_capacity,
+                                               const int32_t* d_n_points, const uint8_t* d_in_view,
+                                               const float* d_proj_xy, const int32_t* d_pred_level,
+                                               const float* d_view_cos, const uint8_t* d_point_descriptors,
+                                               const float* scale_factors, int n_levels, float radius,
+                                               float nn_ratio, int32_t* d_matched, int32_t* d_distance,
+                                               int32_t* d_n_matches) {
+    if (!h || !g || n_pairs <= 0 || !d_frame_index || !d_keypoints || !d_descriptors || !d_counts || !d_cell_start ||
+        !d_cell_items || !d_n_points || !d_in_view || !d_proj_xy || !d_pred_level || !d_view_cos ||
+        !d_point_descriptors || !scale_factors || !d_matched || !d_distance)
+        return ORBX_BAD_ARG;
+    if (kp_capacity <= 0 || points_capacity <= 0 || n_levels <= 0 || n_levels > 64) return ORBX_BAD_ARG;
+    if (g->grid_cols <= 0 || g->grid_rows <= 0 || g->grid_size_x <= 0 || g->grid_size_y <= 0) return ORBX_BAD_ARG;
+    if (kp_capacity > kMaxFeatures) return ORBX_CAPACITY;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_f2.ensure(n_levels));
+    ORBX_TRY(h->d_pushes.ensure((size_t)2 * points_capacity * n_pairs + 2));
+    ORBX_TRY(h->d_ints.ensure(n_pairs));
+    ORBX_HIP(hipMemcpyAsync(h->d_f2.p, scale_factors, sizeof(float) * n_levels, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemsetAsync(h->d_ints.p, 0, sizeof(int32_t) * n_pairs, s));
+    ProjArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.g = *g;
+    A.frame_index = d_frame_index;
+    A.counts = d_counts;
+    A.kp_stride = kp_capacity;
+    A.cell_stride = (size_t)g->grid_cols * g->grid_rows + 1;
+    A.pair_stride = points_capacity;
+    A.out_stride = kp_capacity;
+    A.n_ref_pair = d_n_points;
+    A.ref_desc_per_pair = 1;
+    A.cell_start = d_cell_start;
+    A.cell_items = d_cell_items;
+    A.kps = d_keypoints;
+    A.desc = d_descriptors;
+    A.ref_flag = d_in_view;
+    A.proj_xy = d_proj_xy;
+    A.pred_level = d_pred_level;
+    A.view_cos = d_view_cos;
+    A.ref_desc = d_point_descriptors;
+    A.scale_factors = h->d_f2.p;
+    A.n_levels = n_levels;
+    A.radius = radius;
+    A.nn_ratio = nn_ratio;
+    A.matched = d_matched;
+    A.dists = d_distance;
+    A.pushes = h->d_pushes.p;
+    A.status = h->d_ints.p;
+    A.n_matches = d_n_matches;
+    ORBX_TRY(h->d_win_n.ensure((size_t)points_capacity * n_pairs));
+    ORBX_TRY(h->d_win_list.ensure((size_t)points_capacity * n_pairs * kWinK));
+    ORBX_TRY(h->d_win_over.ensure(n_pairs));
+    ORBX_HIP(hipMemsetAsync(h->d_win_over.p, 0, sizeof(int32_t) * n_pairs, s));
+    A.win_n = h->d_win_n.p;
+    A.win_list = h->d_win_list.p;
+    A.win_stride = kWinK;
+    A.win_overflow = h->d_win_over.p;
+    // the window lists of all points of all pairs are gathered in parallel; the greedy "already matched" rule and the
+    // ratio test inside the candidate loop (orb_matcher.cpp:313-345) are sequential per pair: one wavefront each
+    hipLaunchKernelGGL(k_window_gather<1>, dim3(div_up(points_capacity, 16), n_pairs), dim3(256), 0, s, A);
+    const size_t lds = sizeof(int32_t) * (size_t)kp_capacity;
+    hipLaunchKernelGGL(k_projection_match<1>, dim3(n_pairs), dim3(64), lds, s, A);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
 }

@@ -31,7 +31,7 @@ SYMBOLS = [
     "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
-    "orbx_probe_issue_rate", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
+    "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
     "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
@@ -304,6 +304,18 @@ class Matcher:
         _check(lib().orbx_match_hamming(self._h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)),
                "orbx_match_hamming")
         return idx, dist
+
+    def match_projection_points_batch(self, grid, n_pairs, d_frame_index, d_kps, d_desc, d_counts, kp_capacity,
+                                      d_cell_start, d_cell_items, points_capacity, d_n_points, d_in_view, d_proj_xy,
+                                      d_pred_level, d_view_cos, d_point_desc, scale_factors, radius, nn_ratio,
+                                      d_matched, d_distance, d_n_matches):
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        v = C.c_void_p
+        _check(lib().orbx_match_projection_points_batch(
+            self._h, C.byref(grid), n_pairs, v(d_frame_index), v(d_kps), v(d_desc), v(d_counts), kp_capacity,
+            v(d_cell_start), v(d_cell_items), points_capacity, v(d_n_points), v(d_in_view), v(d_proj_xy),
+            v(d_pred_level), v(d_view_cos), v(d_point_desc), _p(sf), len(sf), C.c_float(radius), C.c_float(nn_ratio),
+            v(d_matched), v(d_distance), v(d_n_matches)), "orbx_match_projection_points_batch")
 
     def match_hamming_batch(self, d_query, d_n_query, query_stride, d_train, d_n_train, train_stride, n_pairs,
                             max_query, max_train, d_idx, d_dist, out_stride):

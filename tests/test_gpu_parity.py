@@ -758,6 +758,81 @@ def test_frame_model_batch_and_batched_projection(oracle, test_images, cap, dist
     mt.close()
 
 
+def test_batched_map_point_projection(oracle, test_images):
+    """orbx_match_projection_points_batch: each pair matches its own list of map points (ragged lengths, some not in
+    view, radii large enough for windows of more than 64 candidates) against one frame of an extracted batch; every
+    pair equals the oracle's BruteForceWithProjectionMatcher::match(frame, points) on the same data."""
+    import torch
+    B, cap, pcap = 4, 1280, 1400
+    cam = orbx.make_camera(517.3, 516.5, 318.6, 255.3, TUM_DIST)
+    ocam = oracle.camera(517.3, 516.5, 318.6, 255.3, TUM_DIST, 640, 480)
+    bounds = oracle.image_bounds(ocam)
+    grid, og = orbx.make_grid(bounds), oracle.grid_params(bounds)
+    frames = [test_images[0], test_images[1], np.roll(test_images[0], 4, axis=1).copy(), synth_image(55, 640, 480, 3)]
+    p = oracle.orb_params(nfeatures=1000)
+    ora = []
+    for img in frames:
+        k = oracle.detect(p, img)
+        xy = oracle.undistort_points(ocam, np.stack([k["x"], k["y"]], 1))
+        k["x"], k["y"] = xy[:, 0], xy[:, 1]
+        k, start, items = oracle.assign_grid(og, k)
+        k2, d = oracle.compute(p, img, k)
+        ora.append((k2, d, start, items))
+    rng = np.random.default_rng(45)
+    pairs = [0, 1, 2, 3, 0, 2]                       # frame of each pair
+    n_pts = [1000, 1400, 37, 0, 640, 999]
+    P = len(pairs)
+    in_view = np.zeros((P, pcap), np.uint8)
+    proj = np.zeros((P, pcap, 2), np.float32)
+    pred = np.zeros((P, pcap), np.int32)
+    vcos = np.zeros((P, pcap), np.float32)
+    pdesc = np.zeros((P, pcap, 32), np.uint8)
+    for i, (f, n) in enumerate(zip(pairs, n_pts)):
+        src_k, src_d = ora[(f + 1) % 4][0], ora[(f + 1) % 4][1]     # points "seen" in the next frame
+        pick = rng.integers(0, len(src_k), n)
+        in_view[i, :n] = rng.uniform(size=n) > 0.15
+        proj[i, :n, 0] = src_k["x"][pick] + rng.normal(0, 3, n)
+        proj[i, :n, 1] = src_k["y"][pick] + rng.normal(0, 3, n)
+        pred[i, :n] = np.clip(src_k["octave"][pick] + rng.integers(-1, 2, n), 0, 7)
+        vcos[i, :n] = rng.uniform(0.99, 1.0, n)
+        pdesc[i, :n] = src_d[pick] ^ (rng.integers(0, 256, (n, 32), dtype=np.uint8) & 0x10)
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=B)
+    ex.set_frame_model(cam, grid)
+    mt = orbx.Matcher()
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), B, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    kp_ptr, desc_ptr, cnt_ptr, kcap = ex.device_results()
+    cs_ptr, ci_ptr = ex.device_grid()
+    _, sf, _, _, _ = ex.scale_tables()
+    d_fi = torch.tensor(pairs, dtype=torch.int32, device="cuda")
+    d_np = torch.tensor(n_pts, dtype=torch.int32, device="cuda")
+    d_iv, d_proj = torch.from_numpy(in_view).cuda(), torch.from_numpy(proj).cuda()
+    d_pred, d_vcos, d_pd = torch.from_numpy(pred).cuda(), torch.from_numpy(vcos).cuda(), torch.from_numpy(pdesc).cuda()
+    d_matched = torch.full((P, cap), 55, dtype=torch.int32, device="cuda")
+    d_dist = torch.zeros((P, cap), dtype=torch.int32, device="cuda")
+    d_nm = torch.zeros(P, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for radius, ratio in ((1.0, 0.6), (4.0, 0.8), (9.0, 0.95)):
+        mt.match_projection_points_batch(grid, P, d_fi.data_ptr(), kp_ptr, desc_ptr, cnt_ptr, cap, cs_ptr, ci_ptr, pcap,
+                                         d_np.data_ptr(), d_iv.data_ptr(), d_proj.data_ptr(), d_pred.data_ptr(),
+                                         d_vcos.data_ptr(), d_pd.data_ptr(), sf, radius, ratio, d_matched.data_ptr(),
+                                         d_dist.data_ptr(), d_nm.data_ptr())
+        torch.cuda.synchronize()
+        hm, hd, hn = d_matched.cpu().numpy(), d_dist.cpu().numpy(), d_nm.cpu().numpy()
+        for i, (f, n) in enumerate(zip(pairs, n_pts)):
+            fk, fd, start, items = ora[f]
+            om = oracle.match_projection_points(og, start, items, fk, fd, in_view[i, :n], proj[i, :n], pred[i, :n],
+                                                vcos[i, :n], pdesc[i, :n], sf, radius, ratio)
+            got_q = np.nonzero(hm[i, :len(fk)] > 0)[0]
+            assert hn[i] == len(om) == len(got_q), (i, radius)
+            assert np.array_equal(got_q, om["query"]) and np.array_equal(hm[i, got_q], om["train"]), (i, radius)
+            assert np.array_equal(hd[i, got_q].astype(np.float32), om["distance"]), (i, radius)
+        assert hn[3] == 0 and hn[0] > 50
+    ex.close()
+    mt.close()
+
+
 def test_batched_projection_crowded_windows(oracle):
     """Windows that hold more acceptable candidates than a pre-sorted list has entries (a cluster of features with
     near-identical descriptors): those points are resolved by the in-kernel window scan, at their turn in the
