@@ -156,6 +156,8 @@ def main():
                          "ranks all-gather their key frames' descriptors and match every frame against all of them")
     ap.add_argument("--frames-4k", type=int, default=32,
                     help="frames per GPU of the 4K extraction leg (3840x2160 gray, 8000 kp, 12 levels; 0 = skip)")
+    ap.add_argument("--fed-frames", type=int, default=1024,
+                    help="frames of the host-fed leg (PCIe-inclusive extraction rate, N = 1 only; 0 = skip)")
     ap.add_argument("--profile-round", default="r02", help="prefix of the PMC summaries under profiles/ to quote")
     args = ap.parse_args()
 
@@ -541,6 +543,39 @@ def main():
                    "stage_ms_per_batch": ex4.last_timings()}
         del f4, ex4, distinct
 
+    # ---- host-fed leg: the same frames start in pinned HOST memory; the feeder uploads one batch ahead on its own
+    # stream while the previous batch is extracted.  Extraction only.  This is the PCIe-inclusive rate, never `value`.
+    fed_line = None
+    if args.fed_frames > 0 and world == 1:
+        FB = 256
+        nb = max(1, args.fed_frames // FB)
+        host = frames[:FB].cpu().repeat((nb, 1, 1, 1)).pin_memory()
+        exf = orbx.Extractor(n_key_points=NKP, level_pyramid=NLEVELS, max_width=W, max_height=H, max_batch=FB,
+                             device=local_rank)
+        fstream = torch.cuda.Stream(device=device)
+        exf.set_stream(fstream.cuda_stream)
+        fd = orbx.Feeder(W, H, 3, FB, n_slots=3)
+
+        def run_fed():
+            fd.start_memory(host.numpy(), already_pinned=True)
+            n = 0
+            while True:
+                ptr, k = fd.next(fstream.cuda_stream)
+                if k == 0:
+                    break
+                exf.extract_batch(ptr, k, W * H * 3, W, H, W * 3, 3, CAP, to_host=False)
+                n += k
+            fstream.synchronize()
+            return n
+        run_fed()
+        q0 = time.perf_counter()
+        n_fed = run_fed()
+        dtf = time.perf_counter() - q0
+        fed_line = {"workload": "640x480 BGR frames in pinned host memory -> upload (double-buffered) -> detect + compute",
+                    "frames": n_fed, "frames_per_s": n_fed / dtf, "bus_GBps": n_fed * W * H * 3 / dtf / 1e9}
+        fd.close()
+        del host, exf, fd
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # up to the whole batch, cut off after about 12 s of CPU work
@@ -559,7 +594,7 @@ def main():
                        "mean_window_matches": mean_matches,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roofline, "roofline_ransac": roofline_ransac, "roofline_match": roofline_match,
-            "ransac": ransac, "extra": {"key_frame_database": kfdb_line, "extraction_4k": line_4k, "issue_rate_probe_lane_ops_per_s": probe},
+            "ransac": ransac, "extra": {"key_frame_database": kfdb_line, "extraction_4k": line_4k, "fed_from_host_memory": fed_line, "issue_rate_probe_lane_ops_per_s": probe},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

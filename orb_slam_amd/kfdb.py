@@ -28,7 +28,7 @@ def gather_database(desc, counts, key_rows, dist=None):
     rows = torch.as_tensor(key_rows, dtype=torch.long, device=desc.device)
     local_desc = desc.index_select(0, rows).contiguous()
     local_counts = counts.index_select(0, rows).contiguous()
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local_desc, local_counts
     world = dist.get_world_size()
     out_d = [torch.empty_like(local_desc) for _ in range(world)]

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 rm -rf $O && mkdir -p $O/summary
 S=$O/summary
-B="--kfdb-frames 0 --frames-4k 0 --no-cpu-baseline"
+B="--kfdb-frames 0 --frames-4k 0 --fed-frames 0 --no-cpu-baseline"
 if [ "$MODE" = full ]; then
   timeout -k 10 300 python3 bench.py > $S/${R}_bench.json
   timeout -k 10 200 python3 bench.py --streams 1 --no-cpu-baseline > $S/${R}_bench_streams1.json
