@@ -15,11 +15,12 @@ constexpr unsigned long long kNoMatch = ~0ull;
 constexpr int kListCap = 2048;   // candidates of one search window
 constexpr int kMaxFeatures = 8192;  // features per frame the windowed matcher keeps flags for in LDS
 
-// K9: brute-force Hamming.  A lane holds kHamQ queries (8 dwords each) in registers; train descriptors are staged
-// through LDS in tiles of 256 and broadcast to all lanes, so one pair of 16-byte LDS reads serves kHamQ x 64
-// descriptor pairs (with one query per lane the LDS pipe, shared by the CU's four SIMDs, was nearly as busy as the
-// vector pipes).  Packed (distance << 32 | train index) keys make the strict-less, lowest-index-wins rule of
-// cv::BFMatcher a plain minimum, so train chunks can be merged with atomicMin.
+// K9: brute-force Hamming.  A lane holds kHamQ queries (8 dwords each) in registers.  A train row is the same for
+// every lane of a wavefront, so it is fetched with SCALAR loads (two rows per 64-byte load) and enters the xor as a
+// scalar operand: no LDS staging, no workgroup barrier, and the vector pipes execute nothing but xor, popcount and
+// the running minimum (17.5 instructions per descriptor pair).  Within a train chunk the key is
+// distance << 16 | row, between chunks distance << 32 | train index: either way the strict-less,
+// lowest-index-wins rule of cv::BFMatcher is a plain minimum, so chunks are merged with atomicMin.
 // popcount(x) + acc in ONE instruction (v_bcnt_u32_b32 adds its second operand).  Left to itself the compiler counts
 // every word into a fresh register and sums them with v_add3_u32: three more half-rate instructions per descriptor pair.
 __device__ __forceinline__ unsigned popc_acc(unsigned x, unsigned acc) {
@@ -29,15 +30,16 @@ __device__ __forceinline__ unsigned popc_acc(unsigned x, unsigned acc) {
 }
 
 __device__ __forceinline__ unsigned hamming256(const uint4& qa, const uint4& qb, const uint4& a, const uint4& b) {
-    // two chains of four, joined by one add: short enough dependency chains, one extra instruction
-    unsigned d0 = popc_acc(qa.x ^ a.x, 0u), d1 = popc_acc(qb.x ^ b.x, 0u);
-    d0 = popc_acc(qa.y ^ a.y, d0);
-    d1 = popc_acc(qb.y ^ b.y, d1);
-    d0 = popc_acc(qa.z ^ a.z, d0);
-    d1 = popc_acc(qb.z ^ b.z, d1);
-    d0 = popc_acc(qa.w ^ a.w, d0);
-    d1 = popc_acc(qb.w ^ b.w, d1);
-    return d0 + d1;
+    // one chain of eight: callers keep several independent distances in flight, which hides the chain's latency
+    unsigned d = popc_acc(qa.x ^ a.x, 0u);
+    d = popc_acc(qb.x ^ b.x, d);
+    d = popc_acc(qa.y ^ a.y, d);
+    d = popc_acc(qb.y ^ b.y, d);
+    d = popc_acc(qa.z ^ a.z, d);
+    d = popc_acc(qb.z ^ b.z, d);
+    d = popc_acc(qa.w ^ a.w, d);
+    d = popc_acc(qb.w ^ b.w, d);
+    return d;
 }
 
 constexpr int kHamQ = 2;               // queries per lane
@@ -48,7 +50,6 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
                                                     const int* __restrict__ nt_arr, int nt_const, size_t t_stride,
                                                     int chunk, unsigned long long* __restrict__ best,
                                                     size_t best_stride) {
-    __shared__ uint4 tile[512];
     const int p = blockIdx.z;
     const int nq = nq_arr ? nq_arr[p] : nq_const;
     const int nt = nt_arr ? nt_arr[p] : nt_const;
@@ -57,8 +58,7 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
     if (blockIdx.x * kHamBlockQ >= nq || t0 >= t1) return;
     // query j of this lane: blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x (adjacent lanes read adjacent rows)
     uint4 qa[kHamQ], qb[kHamQ];
-    unsigned best_d[kHamQ];
-    int best_i[kHamQ];
+    unsigned best_k[kHamQ];
 #pragma unroll
     for (int j = 0; j < kHamQ; j++) {
         const int qi = blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x;
@@ -68,36 +68,59 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
             qa[j] = qp[0];
             qb[j] = qp[1];
         }
-        best_d[j] = 0x7fffffffu;
-        best_i[j] = -1;
+        best_k[j] = 0xffffffffu;
     }
+    // The train row is the same for every lane: its address is uniform, so the compiler fetches it with scalar
+    // loads into scalar registers and the vector pipes see nothing but xor, popcount and the running minimum.
     const uint4* tp = (const uint4*)(t + (size_t)p * t_stride);
-    for (int tb = t0; tb < t1; tb += 256) {
-        __syncthreads();
-        const int j = tb + threadIdx.x;
-        if (j < t1) {
-            tile[2 * threadIdx.x] = tp[2 * (size_t)j];
-            tile[2 * threadIdx.x + 1] = tp[2 * (size_t)j + 1];
-        }
-        __syncthreads();
-        const int cnt = min(256, t1 - tb);
-        for (int k = 0; k < cnt; k++) {
-            const uint4 a = tile[2 * k], b = tile[2 * k + 1];
+    struct Rows2 { uint4 a0, b0, a1, b1; };   // two consecutive train rows: one 64-byte scalar load
+    auto step2 = [&](const Rows2& r, int k) {
+        const unsigned rel = (unsigned)(k - t0);
 #pragma unroll
-            for (int u = 0; u < kHamQ; u++) {
-                const unsigned d = hamming256(qa[u], qb[u], a, b);
-                if (d < best_d[u]) {
-                    best_d[u] = d;
-                    best_i[u] = tb + k;
-                }
-            }
+        for (int u = 0; u < kHamQ; u++) {
+            // key = distance << 16 | row within the chunk: strict-less with the lowest row winning is a plain minimum
+            // (one three-way minimum takes both rows)
+            const unsigned d0 = hamming256(qa[u], qb[u], r.a0, r.b0), d1 = hamming256(qa[u], qb[u], r.a1, r.b1);
+            best_k[u] = min(min(best_k[u], (d0 << 16) + rel), (d1 << 16) + rel + 1u);
         }
+    };
+    auto load2 = [&](int k) { return *(const Rows2*)(tp + 2 * (size_t)k); };
+    // Scalar loads return out of order, so a wait for one of them waits for all that are outstanding.  The loop
+    // therefore keeps exactly one in flight: wait for the rows about to be compared (arrived() makes the compiler
+    // place that wait), THEN issue the load of the rows after them, then compare - the load has the whole
+    // comparison of two rows to arrive.  Past the end the last two rows are taken again (same keys: no change).
+    auto arrived = [](const Rows2& r) { asm volatile("" ::"s"(r.a0.x), "s"(r.b1.w)); };
+    if (t1 - t0 >= 2) {
+        const int last = t1 - 2;
+        int ka = t0;
+        Rows2 A = load2(ka);
+        for (int k = t0; k < t1; k += 4) {
+            const int kb = min(k + 2, last);
+            arrived(A);
+            __builtin_amdgcn_sched_barrier(0);
+            const Rows2 B = load2(kb);
+            __builtin_amdgcn_sched_barrier(0);
+            step2(A, ka);
+            const int kc = min(k + 4, last);
+            arrived(B);
+            __builtin_amdgcn_sched_barrier(0);
+            A = load2(kc);
+            __builtin_amdgcn_sched_barrier(0);
+            step2(B, kb);
+            ka = kc;
+        }
+    } else {
+        Rows2 one;
+        one.a0 = one.a1 = tp[2 * (size_t)t0];
+        one.b0 = one.b1 = tp[2 * (size_t)t0 + 1];
+        step2(one, t0);   // the row twice: its second key is the larger one
     }
 #pragma unroll
     for (int j = 0; j < kHamQ; j++) {
         const int qi = blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x;
-        if (qi < nq && best_i[j] >= 0)
-            atomicMin(&best[(size_t)p * best_stride + qi], ((unsigned long long)best_d[j] << 32) | (unsigned)best_i[j]);
+        if (qi < nq)
+            atomicMin(&best[(size_t)p * best_stride + qi],
+                      ((unsigned long long)(best_k[j] >> 16) << 32) | (unsigned)(t0 + (int)(best_k[j] & 0xffffu)));
     }
 }
 
@@ -1565,7 +1588,8 @@ int pick_chunk(int n_train, int q_blocks, int pairs) {
     int have = std::max(1, q_blocks * pairs);
     int chunks = std::min(std::max(1, want / have), std::max(1, n_train / 256));
     int chunk = div_up(std::max(n_train, 1), chunks);
-    return div_up(chunk, 256) * 256;
+    // at most 2^16 rows per chunk: k_bf_hamming keeps the row within the chunk in 16 bits of its key
+    return std::min(div_up(chunk, 256) * 256, 65536);
 }
 
 }  // namespace
