@@ -371,7 +371,8 @@ __global__ __launch_bounds__(256) void k_resize_strip_sub(uint8_t* __restrict__ 
 // K3+K4a fused: FAST-9/16 score and 3x3 strict non-max suppression of one 64 x kTileH tile, never leaving LDS.
 //   phase 1  every pixel of the tile (plus a one-pixel ring for the suppression) takes the four-point compass test,
 //            four pixels per lane from whole staged dwords, evaluated on 64-bit lane masks with scalar logic; the
-//            pixels that pass (under a tenth) are queued;
+//            pixels that pass (under a tenth) are queued.  Every wavefront has a queue of its own: its fill count
+//            is a scalar register, appending needs no atomic, and phase 2 can start without a workgroup barrier;
 //   phase 2  the queued pixels get their cornerScore with full lanes; the score itself says whether the
 //            nine-contiguous test holds;
 //   phase 3  suppression + border rule for the queued corners -> one mask word per tile row; the score byte is
@@ -382,6 +383,13 @@ constexpr int kFRows = kTileH + 8;
 constexpr int kSW = kTileW + 2, kSH = kTileH + 2;
 constexpr int kFGroups = 18;             // staged dwords per row that can hold a scored pixel (66 columns + alignment)
 constexpr int kQCols = 4 * kFGroups;     // columns a queue entry can name
+constexpr int kFPassRows = 256 / kFGroups;                    // rows of dwords the 256 threads cover per pass (14)
+constexpr int kFPasses = (kSH + kFPassRows - 1) / kFPassRows; // passes over the ring-grown tile (5)
+constexpr int kQSeg = kFPasses * 64 * 4;                      // queue entries one wavefront can produce
+// the last wavefront owns the highest rows of every pass, which the final pass does not reach
+constexpr int kQTotal = 3 * kQSeg + (kFPasses - 1) * 64 * 4;
+static_assert(kFPassRows * kFGroups <= 256 && (kFPasses - 1) * kFPassRows + (192 / kFGroups) >= kSH,
+              "the last wavefront must have no row in the final pass");
 
 // i / D for 0 <= i < 16384 and a small divisor (exact while i * (m * D - 2^20) < 2^20, which the assert bounds): one 24-bit
 // multiply and a shift instead of the quarter-rate 32-bit multiply-high of a general division.
@@ -402,8 +410,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
                                                   int* __restrict__ chunk_counts, int words_per_chunk) {
     __shared__ __align__(16) unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
-    __shared__ unsigned short queue[kQCols * kSH];
-    __shared__ int q_count;
+    __shared__ unsigned short queue[kQTotal];
     // the row masks and their packed scores are first needed in phase 3, when the staged pixels are dead: they share
     // the staging buffer, which brings a tile's LDS under 20 KB - eight tiles per CU instead of seven
     unsigned* s_mask = t32;
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     const LevelInfo L = g.L[tl.level];
     const int b = blockIdx.y + frame0;
     const int aw = g.atlas_w;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lo = max(3, g.edge);
     const bool level_ok = g.edge <= 0 || (L.w > 2 * g.edge && L.h > 2 * g.edge);
     // pixels whose score can matter: the keypoint area [lo, w-lo) grown by one, inside the FAST domain [3, w-3)
@@ -455,86 +462,92 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             if (tid + 256 * k < kSegs) ((uint4*)t32)[tid + 256 * k] = tmp[k];
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
-    if (tid == 0) q_count = 0;
     __syncthreads();
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-    // phase 1: a lane takes the four pixels of one staged dword; rows ys..ye, kFGroups dwords across the tile + ring
-    const int n1 = empty ? 0 : (ye - ys) * kFGroups;
-    for (int base = 0; base < n1; base += 256) {
-        const int item = min(base + tid, n1 - 1);
-        const int r = div_small<kFGroups>(item), gq = item - __mul24(r, kFGroups);
-        const int y = ys + r;
-        const unsigned* tr = t32 + __mul24(y - tl.y0 + 4, kFPitch / 4) + gq;
-        const unsigned C = tr[0], Lw = tr[-1], Rw = tr[1];
-        const unsigned P0 = tr[3 * (kFPitch / 4)], P8 = tr[-3 * (kFPitch / 4)];
-        const unsigned P4 = __builtin_amdgcn_alignbyte(Rw, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
-        // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12), one of {0, 8} and one
-        // of {4, 12}: a corner needs min(max(p0, p8), max(p4, p12)) above the band or max(min(p0, p8), min(p4, p12))
-        // below it.  Both sides fold into ONE compare per pixel, so the scalar unit (one per CU, shared by the four
-        // SIMDs) only counts bits.  Lanes past the end carry a threshold nothing reaches; columns outside the scored
-        // range are dropped when the queue is read (phase 2).
-        const int thr = base + tid < n1 ? threshold : 1024;
-        // two pixels per instruction: even pixels of the dword in one pair of 16-bit halves, odd pixels in another
-        unsigned long long pass[4];
-        bool mine[4];
-        int total = 0;
+    // phase 1: a lane takes the four pixels of one staged dword.  Thread -> (row r0 of a pass, dword gq) once; a pass
+    // covers kFPassRows rows, so everything that depends on the row advances by a constant per pass.
+    unsigned short* wq = queue + wv * kQSeg;   // this wavefront's queue
+    int nq = 0;                                // its fill count (uniform)
+    {
+        const int nrows = empty ? 0 : ye - ys;
+        const int r0 = div_small<kFGroups>(tid), gq = tid - __mul24(r0, kFGroups);
+        const bool in_pass = r0 < kFPassRows;
+        const unsigned* tr = t32 + __mul24(ys - tl.y0 + 4 + r0, kFPitch / 4) + gq;
+        int code = __mul24(r0, kQCols) + 4 * gq;  // (row of the ring-grown tile, staged column)
+        for (int rb = 0; rb < nrows; rb += kFPassRows, tr += kFPassRows * (kFPitch / 4), code += kFPassRows * kQCols) {
+            const bool valid = in_pass && rb + r0 < nrows;
+            // rows past the end read the last staged rows (still inside the buffer: kFPasses * kFPassRows + 3 + 4
+            // rows would be needed at most, so the row index is clamped instead)
+            const unsigned* trc = valid ? tr : t32 + 4 * (kFPitch / 4) + 1;
+            const unsigned C = trc[0], Lw = trc[-1], Rw = trc[1];
+            const unsigned P0 = trc[3 * (kFPitch / 4)], P8 = trc[-3 * (kFPitch / 4)];
+            const unsigned P4 = __builtin_amdgcn_alignbyte(Rw, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
+            // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12), one of {0, 8} and
+            // one of {4, 12}: a corner needs min(max(p0, p8), max(p4, p12)) above the band or
+            // max(min(p0, p8), min(p4, p12)) below it.  Both sides fold into ONE compare per pixel, so the scalar unit
+            // (one per CU, shared by the four SIMDs) only counts bits.  Lanes without a row carry a threshold nothing
+            // reaches; columns outside the scored range are dropped when the queue is read (phase 2).
+            const int thr = valid ? threshold : 1024;
+            // two pixels per instruction: even pixels of the dword in one pair of 16-bit halves, odd pixels in another
+            unsigned long long pass[4];
+            bool mine[4];
+            int total = 0;
 #pragma unroll
-        for (int hsel = 0; hsel < 2; hsel++) {
-            const unsigned sel = hsel ? 0x0c030c01u : 0x0c020c00u;
-            const short2v v = as_short2v(__builtin_amdgcn_perm(0u, C, sel));
-            const short2v p0 = as_short2v(__builtin_amdgcn_perm(0u, P0, sel)), p4 = as_short2v(__builtin_amdgcn_perm(0u, P4, sel));
-            const short2v p8 = as_short2v(__builtin_amdgcn_perm(0u, P8, sel)), p12 = as_short2v(__builtin_amdgcn_perm(0u, P12, sel));
-            const short2v up = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)) - v;
-            const short2v dn = v - __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
-            const short2v m = __builtin_elementwise_max(up, dn);
-            mine[hsel] = m.x > (short)thr;
-            mine[hsel + 2] = m.y > (short)thr;
-            pass[hsel] = __ballot(mine[hsel]);
-            pass[hsel + 2] = __ballot(mine[hsel + 2]);
-            total += __popcll(pass[hsel]) + __popcll(pass[hsel + 2]);
-        }
-        if (total == 0) continue;
-        int qb = 0;
-        if (lane == 0) qb = atomicAdd(&q_count, total);
-        qb = __builtin_amdgcn_readfirstlane(qb);
-        const int code = __mul24(r, kQCols) + 4 * gq;  // (row of the ring-grown tile, staged column)
+            for (int hsel = 0; hsel < 2; hsel++) {
+                const unsigned sel = hsel ? 0x0c030c01u : 0x0c020c00u;
+                const short2v v = as_short2v(__builtin_amdgcn_perm(0u, C, sel));
+                const short2v p0 = as_short2v(__builtin_amdgcn_perm(0u, P0, sel)), p4 = as_short2v(__builtin_amdgcn_perm(0u, P4, sel));
+                const short2v p8 = as_short2v(__builtin_amdgcn_perm(0u, P8, sel)), p12 = as_short2v(__builtin_amdgcn_perm(0u, P12, sel));
+                const short2v up = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)) - v;
+                const short2v dn = v - __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+                const short2v m = __builtin_elementwise_max(up, dn);
+                mine[hsel] = m.x > (short)thr;
+                mine[hsel + 2] = m.y > (short)thr;
+                pass[hsel] = __ballot(mine[hsel]);
+                pass[hsel + 2] = __ballot(mine[hsel + 2]);
+                total += __popcll(pass[hsel]) + __popcll(pass[hsel + 2]);
+            }
+            if (total == 0) continue;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // rank among the passing lanes below this one, counted by the mask-bit-count pair on top of the base
-            if (mine[j])
-                queue[__builtin_amdgcn_mbcnt_hi((unsigned)(pass[j] >> 32),
-                                                __builtin_amdgcn_mbcnt_lo((unsigned)pass[j], (unsigned)qb))] =
-                    (unsigned short)(code + j);
-            qb += __popcll(pass[j]);
+            for (int j = 0; j < 4; j++) {
+                // rank among the passing lanes below this one, counted by the mask-bit-count pair
+                if (mine[j])
+                    wq[nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pass[j] >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)pass[j], 0u))] =
+                        (unsigned short)(code + j);
+                nq += __popcll(pass[j]);
+            }
         }
     }
-    __syncthreads();
+    // the queue was written and is read by this wavefront only: order its LDS traffic, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // phase 2: cornerScore of the queued pixels: max(threshold, best arc-of-9 minimum of |v - p|) - 1
-    const int nq = q_count;
-    for (int q = tid; q < nq; q += 256) {
-        const int code = queue[q];
+    for (int q = lane; q < nq; q += 64) {
+        const int code = wq[q];
         const int rr = div_small<kQCols>(code);
         const int x = tl.x0 - 4 - off + (code - __mul24(rr, kQCols));  // level x of the queued pixel
         if (x < xs || x >= xe) {
-            queue[q] = 0xffffu;
+            wq[q] = 0xffffu;
             continue;
         }
         const int r = ys + rr - tl.y0 + 1, c = x - tl.x0 + 1;   // position in the ring-grown score tile
         const int pos = __mul24(r, kSW) + c;
-        queue[q] = (unsigned short)pos;
+        wq[q] = (unsigned short)pos;
         const uint8_t* ctr = t + __mul24(r + 3, kFPitch) + c + 3 + off;
         const int v = ctr[0];
-        // Pairs of 16-bit halves (d, -d), d = v - ring pixel: the minimum over an arc of nine of the low halves is the
-        // bright-side margin, of the high halves the dark-side one (-max d = min -d), so one packed minimum tree
-        // serves both.  m2/m4/m8: minima over 2, 4, 8 consecutive ring positions starting at k; m9 adds the ninth.
-        const short2v vn = as_short2v(((unsigned)v & 0xffffu) | ((unsigned)(-v) << 16));
-        const short2v sg = {(short)-1, (short)1};
+        // A pair of 16-bit halves (p, -p) per ring pixel p, made by ONE 24-bit multiply: p * -65535 = p - (p << 16).
+        // The minimum of the low halves over an arc of nine is the arc's darkest pixel and of the high halves minus its
+        // brightest one, so one packed minimum tree serves both sides, and the centre value enters only at the end:
+        // bright margin = max over arcs of (min p) - v, dark margin = v - min over arcs of (max p).
+        // m2/m4/m8: minima over 2, 4, 8 consecutive ring positions starting at k; m9 adds the ninth.
         short2v P[16], m2[16], m4[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const unsigned r8 = ctr[dy[k] * kFPitch + dx[k]];
-            P[k] = as_short2v(__umul24(r8, 0x10001u)) * sg + vn;
+            const int r8 = ctr[dy[k] * kFPitch + dx[k]];
+            P[k] = as_short2v((unsigned)__mul24(r8, -65535));
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(P[k], P[(k + 1) & 15]);
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             const short2v m8 = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
             acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(m8, P[(k + 8) & 15]));
         }
-        const int best = max(threshold, max((int)acc.x, (int)acc.y));
+        const int best = max(threshold, max((int)acc.x - v, (int)acc.y + v));
         if (best > threshold) st[pos] = (uint8_t)(best - 1);  // an arc of nine clears the band <=> a corner
     }
     __syncthreads();
@@ -556,8 +569,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     }
     __syncthreads();
     // phase 3: suppression and border rule for the queued corners of the tile proper; bits gathered per tile row
-    for (int q = tid; q < nq; q += 256) {
-        const int pos = queue[q];
+    for (int q = lane; q < nq; q += 64) {
+        const int pos = wq[q];
         if (pos == 0xffff) continue;
         const int c = st[pos];
         const int r = div_small<kSW>(pos) - 1, cc = pos - __mul24(r + 1, kSW) - 1;
@@ -573,12 +586,12 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             }
         }
         if (kp) atomicOr(&s_mask[2 * r + (cc >> 5)], 1u << (cc & 31));
-        else queue[q] = 0xffffu;
+        else wq[q] = 0xffffu;
     }
     __syncthreads();
     // the scores of the first eight keypoints of a row word travel with the word; later ones (rare) go to the plane
-    for (int q = tid; q < nq; q += 256) {
-        const int pos = queue[q];
+    for (int q = lane; q < nq; q += 64) {
+        const int pos = wq[q];
         if (pos == 0xffff) continue;
         const int r = div_small<kSW>(pos) - 1, cc = pos - __mul24(r + 1, kSW) - 1;
         const unsigned long long row = (unsigned long long)s_mask[2 * r] | ((unsigned long long)s_mask[2 * r + 1] << 32);
