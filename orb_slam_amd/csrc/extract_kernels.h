@@ -876,6 +876,9 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
     // lane finishes one candidate when 64 have gathered (and once more at the end).
     int (*res)[6] = s_res[threadIdx.x >> 6];
     int n_res = 0;
+    // the sums of a candidate are ADDED into its parked record (see the reduction below): records start at zero
+#pragma unroll
+    for (int k = 0; k < 6; k++) res[lane][k] = 0;
     auto finish = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -886,12 +889,15 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
             Cand* cp = cbase + res[lane][5];
             cp->harris = resp;
             cp->angle = fast_atan2_deg((float)res[lane][4], (float)res[lane][3]);
+#pragma unroll
+            for (int k = 0; k < 5; k++) res[lane][k] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         n_res = 0;
     };
+    const bool odd = lane & 1, upper = lane & 2;
     Cand c_cur = cbase[min(idx0, max(total - 1, 0))];
     Cand c_nxt = cbase[min(idx0 + stride, max(total - 1, 0))];
     Px px_cur = fetch_px(c_cur, idx0 < total);
@@ -919,17 +925,24 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
                 ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
                 wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
             }
-            const int sha = wave_sum_lane63(ha), shb = wave_sum_lane63(hb), shc = wave_sum_lane63(hc);
-            const int m10 = wave_sum_lane63(right ? (int)wsum : -(int)wsum);
-            const int m01 = wave_sum_lane63(v * (int)ssum);
-            if (lane == 63) {
-                res[n_res][0] = sha;
-                res[n_res][1] = shb;
-                res[n_res][2] = shc;
-                res[n_res][3] = m10;
-                res[n_res][4] = m01;
-                res[n_res][5] = idx;
-            }
+            // Five sums over the wavefront at the price of about two.  Two exchanges inside each quad of lanes fold
+            // four of them into ONE register (lane & 3 = 0: sum Ix^2, 1: sum Iy^2, 2: sum IxIy, 3: m10 - each lane
+            // keeps the quantity of its class and hands the other one to its partner), two row shifts by 4 and 8 leave
+            // every row's class totals in its lanes 12..15, and those 16 lanes add them into the parked record in LDS.
+            // m01 takes the same steps in a register of its own.  All integer: the order of summation is free.
+            const int w10 = right ? (int)wsum : -(int)wsum, w01 = v * (int)ssum;
+            const int x1 = (odd ? hb : ha) + __builtin_amdgcn_update_dpp(0, odd ? ha : hb, 0xB1, 0xF, 0xF, false);
+            const int x2 = (odd ? w10 : hc) + __builtin_amdgcn_update_dpp(0, odd ? hc : w10, 0xB1, 0xF, 0xF, false);
+            int y = w01 + __builtin_amdgcn_update_dpp(0, w01, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+            int z = (upper ? x2 : x1) + __builtin_amdgcn_update_dpp(0, upper ? x1 : x2, 0x4E, 0xF, 0xF, false);
+            y += __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xF, 0xF, false);                  // quad_perm [2,3,0,1]
+            z += __builtin_amdgcn_update_dpp(0, z, 0x114, 0xF, 0xF, true);                  // row_shr:4, zeros shifted in
+            y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
+            z += __builtin_amdgcn_update_dpp(0, z, 0x118, 0xF, 0xF, true);                  // row_shr:8
+            y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
+            if ((lane & 12) == 12) atomicAdd(&res[n_res][lane & 3], z);
+            if ((lane & 15) == 15) atomicAdd(&res[n_res][4], y);
+            if (lane == 63) res[n_res][5] = idx;
             n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
             if (n_res == 64) finish();
         }
@@ -1219,6 +1232,20 @@ __global__ void k_pack_cands(const Cand* __restrict__ cand, int cap, const int* 
 // Reads the un-blurred atlas, writes level interiors (plus at most 3 bytes of never-read border per row end).
 struct BlurTaps { unsigned wa, wb; int k[4]; };
 
+// a * b + c on the low 24 bits of a (wavefront-uniform) and b, in ONE instruction
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// two signed 16-bit halves -> two bytes saturated to 0 .. 255 in the low half of the result
+__device__ __forceinline__ unsigned sat_pk_u8(unsigned two_i16) {
+    unsigned d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(two_i16));
+    return d;
+}
+
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ blurred,
                                               size_t atlas_bytes, Geom g, const Strip* __restrict__ strips,
                                               int n_strips, BlurTaps bt) {
@@ -1246,6 +1273,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
         __builtin_memcpy(&v, src + (so + __umul24((unsigned)min(r, rows + 5), (unsigned)aw)), 12);
         return v;
     };
+    // a multiply-add takes at most one scalar operand: the tap; the rounding constant lives in a vector register
+    // (written by an opaque instruction, or the compiler would re-create it in front of every use)
+    const unsigned kv[4] = {(unsigned)bt.k[0], (unsigned)bt.k[1], (unsigned)bt.k[2], (unsigned)bt.k[3]};
+    unsigned round_half;
+    asm volatile("v_mov_b32 %0, 0x8000" : "=v"(round_half));
     constexpr int kBlurAhead = 8;
     Row3 pf[kBlurAhead];
 #pragma unroll
@@ -1265,17 +1297,22 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ atlas,
                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(rgt, c, 3), bt.wb, 0u, false), false);
         hr[3] = __builtin_amdgcn_udot4(c, bt.wa, __builtin_amdgcn_udot4(rgt, bt.wb, 0u, false), false);
         if (r >= 6) {
-            unsigned out = 0;
+            // rows r-6 .. r hold taps 0 .. 6 (symmetric): k3*h3 + k2*(h2+h4) + k1*(h1+h5) + k0*(h0+h6) + 2^15, as three
+            // full-rate adds and a chain of four 24-bit multiply-adds (taps <= 256, sums < 2^17; left to itself the
+            // compiler multiplies first and sums with three-operand adds, two more half-rate instructions per pixel)
+            unsigned acc[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                // rows r-6 .. r hold taps 0 .. 6 (symmetric): k3*h3 + k2*(h2+h4) + k1*(h1+h5) + k0*(h0+h6)
-                // 24-bit multiplies (full rate; a 32-bit integer multiply issues at a quarter of it): taps <= 256, sums < 2^17
-                const unsigned v = __umul24(bt.k[3], h[(r - 3) % 7][j]) +
-                                   __umul24(bt.k[2], h[(r - 4) % 7][j] + h[(r - 2) % 7][j]) +
-                                   __umul24(bt.k[1], h[(r - 5) % 7][j] + h[(r - 1) % 7][j]) +
-                                   __umul24(bt.k[0], h[(r - 6) % 7][j] + h[r % 7][j]);
-                out |= min((v + (1u << 15)) >> 16, 255u) << (8 * j);
+                acc[j] = mad24(kv[0], h[(r - 6) % 7][j] + h[r % 7][j], round_half);
+                acc[j] = mad24(kv[1], h[(r - 5) % 7][j] + h[(r - 1) % 7][j], acc[j]);
+                acc[j] = mad24(kv[2], h[(r - 4) % 7][j] + h[(r - 2) % 7][j], acc[j]);
+                acc[j] = mad24(kv[3], h[(r - 3) % 7][j], acc[j]);
             }
+            // >> 16 and the clamp to 255 (the taps sum to 257) for two pixels at a time: the upper halves of two sums
+            // side by side are two 16-bit integers, which one instruction narrows to two saturated bytes
+            const unsigned lo = sat_pk_u8(__builtin_amdgcn_perm(acc[1], acc[0], 0x07060302u));
+            const unsigned hi = sat_pk_u8(__builtin_amdgcn_perm(acc[3], acc[2], 0x07060302u));
+            const unsigned out = lo | (hi << 16);
             if (r - 6 < rows) *(unsigned*)(dst + (d_o + __umul24((unsigned)(r - 6), (unsigned)aw))) = out;
         }
     }
