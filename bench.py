@@ -472,6 +472,9 @@ def main():
         kcnt = torch.as_tensor(DevView(cnt_ptr, (KF,), "<i4"), device=device)
         rows = kfdb.keyframe_rows(rank * KF, KF, 10)
         backend = kfdb.HipBackend(mt)
+        # one untimed block against the local key frames: the matcher's workspace is allocated on first use
+        kfdb.match_frames_against_database(backend, kdesc, kcnt, kdesc[rows].contiguous(), kcnt[rows].contiguous(),
+                                           frames=range(min(8, KF)), consume=lambda f, i, d: None)
         barrier()
         k0 = time.perf_counter()
         db_desc, db_counts = kfdb.gather_database(kdesc, kcnt, rows, dist if world > 1 else None)

@@ -172,6 +172,15 @@ orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, co
                                      size_t train_stride, int n_pairs, int max_query, int max_train,
                                      int32_t* d_train_idx, int32_t* d_distance, size_t out_stride);
 
+/* The same match (orb_matcher.cpp:671-677) for EVERY query set against EVERY train set in one call - the many-to-many
+   matching of frames against a key-frame database: pair p = q * n_train_sets + t matches query set q
+   (d_query + q*query_stride, n_query[q] rows) against train set t (d_train + t*train_stride, n_train[t] rows); results
+   at [p*out_stride + i].  n_query_sets * n_train_sets <= 65535. */
+orbx_status orbx_match_hamming_cross(orbx_matcher* h, const uint8_t* d_query, const int32_t* d_n_query,
+                                     size_t query_stride, int n_query_sets, const uint8_t* d_train,
+                                     const int32_t* d_n_train, size_t train_stride, int n_train_sets, int max_query,
+                                     int max_train, int32_t* d_train_idx, int32_t* d_distance, size_t out_stride);
+
 /* Replaces ORBMatcher::filterMatches (orb_matcher.cpp:890-924).  Host arithmetic (sort + unique with the same
    std:: calls).  In place; *count updated.  n_descriptor_rows = descriptors.rows of the reference call. */
 orbx_status orbx_filter_matches(orbx_match* matches, int* count, int n_descriptor_rows);

@@ -49,10 +49,13 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
                                                     int nq_const, size_t q_stride, const uint8_t* __restrict__ t,
                                                     const int* __restrict__ nt_arr, int nt_const, size_t t_stride,
                                                     int chunk, unsigned long long* __restrict__ best,
-                                                    size_t best_stride) {
+                                                    size_t best_stride, int t_sets) {
+    // pair p compares query set qs with train set ts: qs = ts = p, or (t_sets > 0) every query set with every
+    // train set, p = qs * t_sets + ts
     const int p = blockIdx.z;
-    const int nq = nq_arr ? nq_arr[p] : nq_const;
-    const int nt = nt_arr ? nt_arr[p] : nt_const;
+    const int qs = t_sets > 0 ? p / t_sets : p, ts = t_sets > 0 ? p - qs * t_sets : p;
+    const int nq = nq_arr ? nq_arr[qs] : nq_const;
+    const int nt = nt_arr ? nt_arr[ts] : nt_const;
     const int t0 = blockIdx.y * chunk;
     const int t1 = min(nt, t0 + chunk);
     if (blockIdx.x * kHamBlockQ >= nq || t0 >= t1) return;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
         const int qi = blockIdx.x * kHamBlockQ + j * 256 + threadIdx.x;
         qa[j] = qb[j] = make_uint4(0, 0, 0, 0);
         if (qi < nq) {
-            const uint4* qp = (const uint4*)(q + (size_t)p * q_stride + (size_t)qi * 32);
+            const uint4* qp = (const uint4*)(q + (size_t)qs * q_stride + (size_t)qi * 32);
             qa[j] = qp[0];
             qb[j] = qp[1];
         }
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
     }
     // The train row is the same for every lane: its address is uniform, so the compiler fetches it with scalar
     // loads into scalar registers and the vector pipes see nothing but xor, popcount and the running minimum.
-    const uint4* tp = (const uint4*)(t + (size_t)p * t_stride);
+    const uint4* tp = (const uint4*)(t + (size_t)ts * t_stride);
     struct Rows2 { uint4 a0, b0, a1, b1; };   // two consecutive train rows: one 64-byte scalar load
     auto step2 = [&](const Rows2& r, int k) {
         const unsigned rel = (unsigned)(k - t0);
@@ -126,9 +129,9 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
 
 __global__ void k_unpack_best(const unsigned long long* __restrict__ best, size_t best_stride,
                               const int* __restrict__ nq_arr, int nq_const, int32_t* __restrict__ idx,
-                              int32_t* __restrict__ dist, size_t out_stride) {
+                              int32_t* __restrict__ dist, size_t out_stride, int t_sets) {
     const int p = blockIdx.y;
-    const int nq = nq_arr ? nq_arr[p] : nq_const;
+    const int nq = nq_arr ? nq_arr[t_sets > 0 ? p / t_sets : p] : nq_const;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const unsigned long long k = best[(size_t)p * best_stride + i];
@@ -1592,6 +1595,34 @@ int pick_chunk(int n_train, int q_blocks, int pairs) {
     return std::min(div_up(chunk, 256) * 256, 65536);
 }
 
+// Pairs of descriptor sets through k_bf_hamming: pair p = (query set p, train set p), or with t_sets > 0 every query
+// set against every train set (p = query set * t_sets + train set).  Outputs per pair, out_stride values apart.
+orbx_status hamming_sets(orbx_matcher* h, const uint8_t* d_query, const int32_t* d_n_query, size_t query_stride,
+                         const uint8_t* d_train, const int32_t* d_n_train, size_t train_stride, int n_pairs, int t_sets,
+                         int max_query, int max_train, int32_t* d_train_idx, int32_t* d_distance, size_t out_stride) {
+    if (!h || !d_query || !d_train || !d_train_idx || !d_distance) return ORBX_BAD_ARG;
+    if (n_pairs <= 0 || n_pairs > 65535 || max_query < 0 || max_train < 0 || out_stride < (size_t)max_query)
+        return ORBX_BAD_ARG;
+    if (max_query == 0) return ORBX_OK;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    size_t nb = (size_t)n_pairs * max_query;
+    ORBX_TRY(h->d_best.ensure(nb));
+    ORBX_HIP(hipMemsetAsync(h->d_best.p, 0xff, nb * sizeof(unsigned long long), s));
+    const int qb = div_up(max_query, 256);
+    if (max_train > 0) {
+        const int hb = div_up(max_query, kHamBlockQ);
+        const int chunk = pick_chunk(max_train, hb, n_pairs);
+        dim3 grid(hb, div_up(max_train, chunk), n_pairs);
+        hipLaunchKernelGGL(k_bf_hamming, grid, dim3(256), 0, s, d_query, d_n_query, max_query, query_stride, d_train,
+                           d_n_train, max_train, train_stride, chunk, h->d_best.p, (size_t)max_query, t_sets);
+    }
+    hipLaunchKernelGGL(k_unpack_best, dim3(qb, n_pairs), dim3(256), 0, s, h->d_best.p, (size_t)max_query, d_n_query,
+                       max_query, d_train_idx, d_distance, out_stride, t_sets);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1632,26 +1663,18 @@ orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, co
                                      size_t query_stride, const uint8_t* d_train, const int32_t* d_n_train,
                                      size_t train_stride, int n_pairs, int max_query, int max_train,
                                      int32_t* d_train_idx, int32_t* d_distance, size_t out_stride) {
-    if (!h || !d_query || !d_train || !d_train_idx || !d_distance) return ORBX_BAD_ARG;
-    if (n_pairs <= 0 || max_query < 0 || max_train < 0 || out_stride < (size_t)max_query) return ORBX_BAD_ARG;
-    if (max_query == 0) return ORBX_OK;
-    ORBX_HIP(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    size_t nb = (size_t)n_pairs * max_query;
-    ORBX_TRY(h->d_best.ensure(nb));
-    ORBX_HIP(hipMemsetAsync(h->d_best.p, 0xff, nb * sizeof(unsigned long long), s));
-    const int qb = div_up(max_query, 256);
-    if (max_train > 0) {
-        const int hb = div_up(max_query, kHamBlockQ);
-        const int chunk = pick_chunk(max_train, hb, n_pairs);
-        dim3 grid(hb, div_up(max_train, chunk), n_pairs);
-        hipLaunchKernelGGL(k_bf_hamming, grid, dim3(256), 0, s, d_query, d_n_query, max_query, query_stride, d_train,
-                           d_n_train, max_train, train_stride, chunk, h->d_best.p, (size_t)max_query);
-    }
-    hipLaunchKernelGGL(k_unpack_best, dim3(qb, n_pairs), dim3(256), 0, s, h->d_best.p, (size_t)max_query, d_n_query,
-                       max_query, d_train_idx, d_distance, out_stride);
-    ORBX_HIP(hipGetLastError());
-    return ORBX_OK;
+    return hamming_sets(h, d_query, d_n_query, query_stride, d_train, d_n_train, train_stride, n_pairs, 0, max_query,
+                        max_train, d_train_idx, d_distance, out_stride);
+}
+
+orbx_status orbx_match_hamming_cross(orbx_matcher* h, const uint8_t* d_query, const int32_t* d_n_query,
+                                     size_t query_stride, int n_query_sets, const uint8_t* d_train,
+                                     const int32_t* d_n_train, size_t train_stride, int n_train_sets, int max_query,
+                                     int max_train, int32_t* d_train_idx, int32_t* d_distance, size_t out_stride) {
+    if (n_query_sets <= 0 || n_train_sets <= 0 || (long long)n_query_sets * n_train_sets > 65535) return ORBX_BAD_ARG;
+    return hamming_sets(h, d_query, d_n_query, query_stride, d_train, d_n_train, train_stride,
+                        n_query_sets * n_train_sets, n_train_sets, max_query, max_train, d_train_idx, d_distance,
+                        out_stride);
 }
 
 orbx_status orbx_match_hamming(orbx_matcher* h, const uint8_t* query, int n_query, const uint8_t* train, int n_train,

@@ -8,8 +8,8 @@ its frames against every key frame of the database: per (frame, key frame) pair 
 lowest index on ties).
 
 The matching call is a backend object, so that the same driver runs on the GPU (HipBackend: the C ABI's
-orbx_match_hamming_batch, one call per frame with the query block shared by all pairs) and in the CPU tests of the
-multi-rank path (a stand-in backend with the same contract).
+orbx_match_hamming_cross, one call per block of frames: every frame of the block against every key frame) and in the
+CPU tests of the multi-rank path (a stand-in backend with the same contract).
 """
 import numpy as np
 
@@ -39,15 +39,15 @@ def gather_database(desc, counts, key_rows, dist=None):
 
 
 class HipBackend:
-    """orbx_match_hamming_batch on device tensors: pair k of a call = (the frame's rows, key frame k's rows)."""
+    """orbx_match_hamming_cross on device tensors: pair f * K + k of a call = (frame f's rows, key frame k's rows)."""
 
     def __init__(self, matcher):
         self.matcher = matcher
 
-    def match(self, query, n_query_rep, db_desc, db_counts, out_idx, out_dist):
-        """query [cap, 32]; n_query_rep [K] (the frame's row count repeated); outputs [K, cap] int32."""
-        K, cap = db_desc.shape[0], db_desc.shape[1]
-        self.matcher.match_hamming_batch(query.data_ptr(), n_query_rep.data_ptr(), 0, db_desc.data_ptr(),
+    def match(self, queries, n_query, db_desc, db_counts, out_idx, out_dist):
+        """queries [F, cap, 32], n_query [F]; outputs [F, K, cap] int32 (rows past a frame's count are not written)."""
+        F, K, cap = queries.shape[0], db_desc.shape[0], db_desc.shape[1]
+        self.matcher.match_hamming_cross(queries.data_ptr(), n_query.data_ptr(), cap * 32, F, db_desc.data_ptr(),
                                          db_counts.data_ptr(), cap * 32, K, cap, cap, out_idx.data_ptr(),
                                          out_dist.data_ptr(), cap)
 
@@ -57,47 +57,57 @@ class NumpyBackend:
 
     _POP = np.array([bin(i).count("1") for i in range(256)], np.int32)
 
-    def match(self, query, n_query_rep, db_desc, db_counts, out_idx, out_dist):
-        q = query.numpy()
-        for k in range(db_desc.shape[0]):
-            nq, nt = int(n_query_rep[k]), int(db_counts[k])
-            if nq == 0:
-                continue
-            if nt == 0:
-                out_idx[k, :nq] = -1
-                out_dist[k, :nq] = -1
-                continue
-            t = db_desc[k, :nt].numpy()
-            d = self._POP[q[:nq, None, :] ^ t[None, :, :]].sum(2)
-            best = d.argmin(1)  # first minimum: lowest train index on ties
-            import torch
-            out_idx[k, :nq] = torch.from_numpy(best.astype(np.int32))
-            out_dist[k, :nq] = torch.from_numpy(d[np.arange(nq), best].astype(np.int32))
+    def match(self, queries, n_query, db_desc, db_counts, out_idx, out_dist):
+        import torch
+        for f in range(queries.shape[0]):
+            q = queries[f].numpy()
+            nq = int(n_query[f])
+            for k in range(db_desc.shape[0]):
+                nt = int(db_counts[k])
+                if nq == 0:
+                    continue
+                if nt == 0:
+                    out_idx[f, k, :nq] = -1
+                    out_dist[f, k, :nq] = -1
+                    continue
+                t = db_desc[k, :nt].numpy()
+                d = self._POP[q[:nq, None, :] ^ t[None, :, :]].sum(2)
+                best = d.argmin(1)  # first minimum: lowest train index on ties
+                out_idx[f, k, :nq] = torch.from_numpy(best.astype(np.int32))
+                out_dist[f, k, :nq] = torch.from_numpy(d[np.arange(nq), best].astype(np.int32))
 
 
-def match_frames_against_database(backend, desc, counts, db_desc, db_counts, frames=None, consume=None):
-    """Matches each local frame (all, or the indices in `frames`) against every key frame of the database.
-    consume(frame, idx [K, cap], dist [K, cap]) is called per frame with buffers that are reused by the next frame;
-    without it the per-frame results are stacked and returned as ([frames, K, cap], [frames, K, cap]), -1 in the rows
-    past a frame's count.  On the GPU the matcher must launch on the stream torch is using (Matcher.set_stream)."""
+def match_frames_against_database(backend, desc, counts, db_desc, db_counts, frames=None, consume=None, block=8):
+    """Matches each local frame (all, or the indices in `frames`) against every key frame of the database, `block`
+    frames per call of the backend.  consume(frame, idx [K, cap], dist [K, cap]) is called per frame with buffers that
+    are reused by a later block; without it the per-frame results are stacked and returned as ([frames, K, cap],
+    [frames, K, cap]), -1 in the rows past a frame's count.  On the GPU the matcher must launch on the stream torch is
+    using (Matcher.set_stream)."""
     import torch
     K, cap = db_desc.shape[0], db_desc.shape[1]
     frames = list(range(desc.shape[0])) if frames is None else list(frames)
-    n_rep = counts[:, None].expand(counts.shape[0], K).contiguous()
-    out_idx = torch.zeros((K, cap), dtype=torch.int32, device=desc.device)
-    out_dist = torch.zeros((K, cap), dtype=torch.int32, device=desc.device)
+    block = max(1, min(block, 65535 // max(K, 1)))
+    out_idx = torch.zeros((block, K, cap), dtype=torch.int32, device=desc.device)
+    out_dist = torch.zeros((block, K, cap), dtype=torch.int32, device=desc.device)
     kept_i, kept_d = [], []
-    for f in frames:
+    for b0 in range(0, len(frames), block):
+        fb = frames[b0:b0 + block]
+        if fb == list(range(fb[0], fb[0] + len(fb))):
+            q, nq = desc[fb[0]:fb[0] + len(fb)], counts[fb[0]:fb[0] + len(fb)]   # consecutive frames: views, no copy
+        else:
+            sel = torch.as_tensor(fb, dtype=torch.long, device=desc.device)
+            q, nq = desc.index_select(0, sel), counts.index_select(0, sel)
         if consume is None:
             # rows past a frame's count are not written by the matcher: give them one value for every frame
             out_idx.fill_(-1)
             out_dist.fill_(-1)
-        backend.match(desc[f], n_rep[f], db_desc, db_counts, out_idx, out_dist)
-        if consume is not None:
-            consume(f, out_idx, out_dist)
-        else:
-            kept_i.append(out_idx.clone())
-            kept_d.append(out_dist.clone())
+        backend.match(q.contiguous(), nq.contiguous(), db_desc, db_counts, out_idx[:len(fb)], out_dist[:len(fb)])
+        for j, f in enumerate(fb):
+            if consume is not None:
+                consume(f, out_idx[j], out_dist[j])
+            else:
+                kept_i.append(out_idx[j].clone())
+                kept_d.append(out_dist[j].clone())
     if consume is not None:
         return None
     return torch.stack(kept_i), torch.stack(kept_d)

@@ -23,7 +23,7 @@ SYMBOLS = [
     "orbx_extractor_create", "orbx_extractor_destroy", "orbx_extractor_scale_tables", "orbx_detect", "orbx_compute",
     "orbx_extract_batch", "orbx_extractor_device_results", "orbx_extractor_layout", "orbx_extractor_read_plane",
     "orbx_extractor_last_timings", "orbx_matcher_create", "orbx_matcher_destroy", "orbx_match_hamming",
-    "orbx_match_hamming_batch", "orbx_filter_matches", "orbx_match_radius", "orbx_assign_grid",
+    "orbx_match_hamming_batch", "orbx_match_hamming_cross", "orbx_filter_matches", "orbx_match_radius", "orbx_assign_grid",
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_batch_static", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
@@ -324,6 +324,15 @@ class Matcher:
                                               C.c_size_t(train_stride), n_pairs, max_query, max_train,
                                               C.c_void_p(d_idx), C.c_void_p(d_dist), C.c_size_t(out_stride)),
                "orbx_match_hamming_batch")
+
+    def match_hamming_cross(self, d_query, d_n_query, query_stride, n_query_sets, d_train, d_n_train, train_stride,
+                            n_train_sets, max_query, max_train, d_idx, d_dist, out_stride):
+        """Every query set against every train set (device pointers); pair q * n_train_sets + t."""
+        _check(lib().orbx_match_hamming_cross(self._h, C.c_void_p(d_query), C.c_void_p(d_n_query),
+                                              C.c_size_t(query_stride), n_query_sets, C.c_void_p(d_train),
+                                              C.c_void_p(d_n_train), C.c_size_t(train_stride), n_train_sets,
+                                              max_query, max_train, C.c_void_p(d_idx), C.c_void_p(d_dist),
+                                              C.c_size_t(out_stride)), "orbx_match_hamming_cross")
 
     def match(self, descriptors, ref_descriptors, filter_matches=True):
         """ORBMatcher::match(descriptors, ref_descriptors, matches, filter) (orb_matcher.cpp:719-733)."""

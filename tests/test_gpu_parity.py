@@ -438,6 +438,21 @@ def test_match_hamming_batch_ragged_pairs(oracle, matcher):
             oi, od = oracle.match_hamming(q[p, :nq], t[p, :nt])
             assert np.array_equal(idx[p, :nq], oi) and np.array_equal(dist[p, :nq], od), (p, nq, nt)
         assert (idx[p, nq:] == -7).all()                              # rows past a pair's count are not written
+    # every query set against every train set in one call (pair q * n_train_sets + t), sets 3..8 against sets 2..9
+    QS, TS = list(range(3, 9)), list(range(2, 10))
+    c_idx = torch.full((len(QS) * len(TS), cap_q), -7, dtype=torch.int32, device="cuda")
+    c_dist = torch.full_like(c_idx, -7)
+    matcher.match_hamming_cross(d_q[3:].data_ptr(), d_nq[3:].data_ptr(), cap_q * 32, len(QS), d_t[2:].data_ptr(),
+                                d_nt[2:].data_ptr(), cap_t * 32, len(TS), cap_q, cap_t, c_idx.data_ptr(),
+                                c_dist.data_ptr(), cap_q)
+    torch.cuda.synchronize()
+    ci, cd = c_idx.cpu().numpy(), c_dist.cpu().numpy()
+    for a, qs in enumerate(QS):
+        for b, tset in enumerate(TS):
+            nq, nt = sizes[qs][0], sizes[tset][1]
+            oi, od = oracle.match_hamming(q[qs, :nq], t[tset, :nt])
+            assert np.array_equal(ci[a * len(TS) + b, :nq], oi) and np.array_equal(cd[a * len(TS) + b, :nq], od), (qs, tset)
+            assert (ci[a * len(TS) + b, nq:] == -7).all()
     # the key-frame database driver: 6 frames against 4 key frames
     desc = torch.from_numpy(q[3:9, :600].copy())
     counts = torch.tensor([255, 256, 257, 511, 512, 513], dtype=torch.int32)
@@ -447,7 +462,7 @@ def test_match_hamming_batch_ragged_pairs(oracle, matcher):
     with torch.cuda.stream(ts):
         matcher.set_stream(ts.cuda_stream)
         got_i, got_d = kfdb.match_frames_against_database(kfdb.HipBackend(matcher), desc.cuda(), counts.cuda(),
-                                                          db_desc.cuda(), db_counts.cuda())
+                                                          db_desc.cuda(), db_counts.cuda(), block=4)
     torch.cuda.synchronize()
     matcher.set_stream(0)
     for f in range(6):
