@@ -99,9 +99,11 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
    the handle's stream: the device results (orbx_extractor_device_results / _device_grid) may be consumed by work
    queued on the same stream right away, and the host never waits inside the call.  orbx_extractor_finish then waits
    for that batch and reports what the synchronous call would have returned: ORBX_CAPACITY when a frame has more
-   keypoints than `capacity`; counts[n_frames] when non-NULL.  *redone = 1 (when non-NULL) says that a frame had
-   more candidates than the on-device selection holds and the batch was finished by the host selection inside this
-   call: the device results are now the final ones, and whatever consumed them before has to run again.  A batch
+   keypoints than `capacity`; counts[n_frames] when non-NULL.  *redone = 1 (when non-NULL) says that frames were
+   left over by the queued selection (more frames beyond the LDS form than the global form has workspace slices, or a
+   candidate list that overflowed) and the batch was finished inside this call - by further device passes, or by the
+   host selection for an overflowed list: the device results are now the final ones, and whatever consumed them
+   before has to run again.  A batch
    that was never finished is waited for and dropped by the next call on the handle.  No counterpart in the
    reference (its extraction is synchronous). */
 orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redone);

@@ -85,6 +85,9 @@ struct orbx_extractor {
     PinBuf<int32_t> h_cell_start, h_cell_items;
     DevBuf<int> d_status;
     DevBuf<unsigned char> d_select_ws;  // workspace of the selection kernel's global form
+    FrameModel sel_fm;                  // what the last device selection ran with (more_global_passes repeats it)
+    size_t sel_ws_stride = 0;
+    int sel_ws_slices = 0;
     bool device_select = true;     // batch path: select / undistort / grid on the device (k_select_frame)
     bool select_attr_set = false;
     size_t select_attr_bytes = 0;
@@ -903,6 +906,43 @@ orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int
 
 }  // extern "C"
 
+// Frames the device selection left at status 2 because the global form ran out of workspace slices (more frames
+// beyond the LDS form than slices) get further passes of the global form, a slice-load at a time; the describe stage is
+// then repeated for the batch.  Returns with *left = number of frames still at status 2 (their candidate list itself
+// overflowed: the host path enlarges it).  The status and count words are in h->h_ints when this returns.
+static orbx_status more_global_passes(orbx_extractor* h, int n_frames, int capacity, int* left) {
+    int* h_status = h->h_ints.p;
+    int* h_cnt = h->h_ints.p + n_frames;
+    auto count_left = [&]() {
+        int n = 0;
+        for (int f = 0; f < n_frames; f++) n += h_status[f] == 2;
+        return n;
+    };
+    int before = count_left();
+    *left = before;
+    if (h->sel_ws_slices <= 0) return ORBX_OK;
+    int* ws_counter = (int*)(h->d_select_ws.p + h->sel_ws_stride * h->sel_ws_slices);
+    while (before > 0) {
+        ORBX_HIP(hipMemsetAsync(ws_counter, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_select_frame<true>, dim3(n_frames), dim3(64 * h->geom.nlevels), 0, h->stream, h->d_cand.p,
+                           h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, h->sel_fm, h->d_kp.p, capacity,
+                           h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p, h->cand_cap, 2,
+                           h->d_select_ws.p, h->sel_ws_stride, h->sel_ws_slices, ws_counter);
+        ORBX_HIP(hipMemcpyAsync(h_status, h->d_status.p, sizeof(int) * n_frames, hipMemcpyDeviceToHost, h->stream));
+        ORBX_HIP(hipMemcpyAsync(h_cnt, h->d_kp_counts.p, sizeof(int) * n_frames, hipMemcpyDeviceToHost, h->stream));
+        ORBX_HIP(hipStreamSynchronize(h->stream));
+        const int now = count_left();
+        if (now >= before) break;  // no progress: what is left overflowed the candidate list
+        before = now;
+    }
+    *left = before;
+    if (before == 0) {
+        ORBX_TRY(run_describe_stage(h, n_frames));
+        ORBX_HIP(hipStreamSynchronize(h->stream));
+    }
+    return ORBX_OK;
+}
+
 // orbx_extract_batch from the selection on, by the host path: candidates are downloaded, cv::ORB's two retainBest
 // culls run with the real std:: calls, then undistortion, grid and border filter as MonoFrame::extractFeatures does
 // them (mono_frame.cpp:85-100), and the keypoints go back to the device for the describe stage.  No limit on
@@ -1056,6 +1096,9 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         ORBX_TRY(h->d_select_ws.ensure(ws_stride * ws_slices + sizeof(int) * 64));
         int* ws_counter = (int*)(h->d_select_ws.p + ws_stride * ws_slices);
         ORBX_HIP(hipMemsetAsync(ws_counter, 0, sizeof(int), h->stream));
+        h->sel_fm = fm;
+        h->sel_ws_stride = ws_stride;
+        h->sel_ws_slices = ws_slices;
         h->timer.begin(ST_SELECT, h->stream);
         auto launch_global = [&](int pass) {
             hipLaunchKernelGGL(k_select_frame<true>, dim3(n_frames), dim3(64 * h->geom.nlevels), 0, h->stream,
@@ -1128,6 +1171,20 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
             if (h_status[f] == 1) return ORBX_CAPACITY;
             if (h_status[f] == 2) redo = true;
         }
+        if (redo) {
+            int left = 0;
+            ORBX_TRY(more_global_passes(h, n_frames, capacity, &left));
+            redo = left > 0;
+            for (int f = 0; f < n_frames; f++)
+                if (h_status[f] == 1) return ORBX_CAPACITY;
+            if (!redo) {
+                if (keypoints)
+                    ORBX_HIP(hipMemcpy(keypoints, h->d_kp.p, sizeof(orbx_keypoint) * (size_t)capacity * n_frames,
+                                       hipMemcpyDeviceToHost));
+                if (descriptors)
+                    ORBX_HIP(hipMemcpy(descriptors, h->d_desc.p, (size_t)capacity * n_frames * 32, hipMemcpyDeviceToHost));
+            }
+        }
         if (!redo) {
             h->last_counts.assign(h_cnt, h_cnt + n_frames);
             if (counts) std::memcpy(counts, h_cnt, sizeof(int) * n_frames);
@@ -1162,10 +1219,20 @@ orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redon
         if (counts) std::memcpy(counts, h_cnt, sizeof(int) * a.n_frames);
         return ORBX_OK;
     }
-    // a frame had more candidates than the device selection holds: the batch is finished by the host path, and
+    // frames were left over (more of them beyond the LDS form than workspace slices, or a candidate list that
+    // overflowed): the batch is finished by further device passes or, for an overflowed list, by the host path, and
     // whatever consumed the device results in the meantime has to run again
     if (redone) *redone = 1;
     BlurForkGuard fork_guard{h};
+    int left = 0;
+    ORBX_TRY(more_global_passes(h, a.n_frames, a.capacity, &left));
+    for (int f = 0; f < a.n_frames; f++)
+        if (h_status[f] == 1) return ORBX_CAPACITY;
+    if (left == 0) {
+        h->last_counts.assign(h_cnt, h_cnt + a.n_frames);
+        if (counts) std::memcpy(counts, h_cnt, sizeof(int) * a.n_frames);
+        return ORBX_OK;
+    }
     return batch_host_path(h, a.n_frames, a.width, a.height, a.capacity, nullptr, counts, nullptr);
 }
 

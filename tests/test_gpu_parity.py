@@ -347,6 +347,23 @@ def test_selection_of_a_frame_beyond_the_lds_form(oracle, test_images):
             assert np.array_equal(kps[f, :counts[f]], ok_.astype(orbx.KP_DTYPE)), (cap, f)
             assert np.array_equal(desc[f, :counts[f]], od), (cap, f)
     ex.close()
+    # more such frames in one batch than the global form has workspace slices (8): the rest get further passes of the
+    # same kernel, still on the device, and finish() reports that consumers of the device results must run again
+    order = [1, 3] * 5 + [0]
+    many = torch.from_numpy(np.stack([frames[i] for i in order])).cuda()
+    torch.cuda.synchronize()
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(order))
+    ex.extract_batch(many.data_ptr(), len(order), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1280, to_host=False, deferred=True)
+    counts, redone = ex.finish()
+    assert redone
+    kps, c2, desc = ex.extract_batch(many.data_ptr(), len(order), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1280)
+    assert np.array_equal(counts, c2)
+    for f, src in enumerate(order):
+        ok_, od = ora[src]
+        assert counts[f] == len(ok_), f
+        assert np.array_equal(kps[f, :counts[f]], ok_.astype(orbx.KP_DTYPE)), f
+        assert np.array_equal(desc[f, :counts[f]], od), f
+    ex.close()
 
 
 def test_extract_batch_ragged_inputs(oracle):
