@@ -168,7 +168,8 @@ orbx_status orbx_match_hamming(orbx_matcher* h, const uint8_t* query, int n_quer
                                int n_train, int32_t* train_idx, int32_t* distance);
 
 /* Batched form on device-resident descriptors: pair p matches d_query + p*query_stride (n_query[p] rows) against
-   d_train + p*train_stride (n_train[p] rows); results d_train_idx/d_distance[p*out_stride + i] (device). */
+   d_train + p*train_stride (n_train[p] rows); results d_train_idx/d_distance[p*out_stride + i] (device).
+   Descriptor blocks and strides must be multiples of 16 bytes; at most 65 535 pairs per call. */
 orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, const int32_t* d_n_query,
                                      size_t query_stride, const uint8_t* d_train, const int32_t* d_n_train,
                                      size_t train_stride, int n_pairs, int max_query, int max_train,

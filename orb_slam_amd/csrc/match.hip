@@ -1603,6 +1603,8 @@ orbx_status hamming_sets(orbx_matcher* h, const uint8_t* d_query, const int32_t*
     if (!h || !d_query || !d_train || !d_train_idx || !d_distance) return ORBX_BAD_ARG;
     if (n_pairs <= 0 || n_pairs > 65535 || max_query < 0 || max_train < 0 || out_stride < (size_t)max_query)
         return ORBX_BAD_ARG;
+    // descriptor rows are read as 16-byte words (queries) and by 64-byte scalar loads (train rows)
+    if ((((uintptr_t)d_query | (uintptr_t)d_train | query_stride | train_stride) & 15) != 0) return ORBX_BAD_ARG;
     if (max_query == 0) return ORBX_OK;
     ORBX_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
