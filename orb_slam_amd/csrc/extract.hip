@@ -1032,6 +1032,7 @@ static orbx_status batch_host_path(orbx_extractor* h, int n_frames, int width, i
 
 extern "C" {
 
+
 orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n_frames, size_t frame_stride,
                                int width, int height, int stride, int channels, orbx_keypoint* keypoints,
                                int capacity, int32_t* counts, uint8_t* descriptors) {
@@ -1057,8 +1058,10 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     const size_t select_lds_full = sizeof(stdsel::Elem) * (size_t)kSelectMaxCands +
                                    std::max((size_t)capacity * (sizeof(orbx_keypoint) + sizeof(int)),
                                             sizeof(uint16_t) * 2 * (size_t)kSelectMaxCands);
-    const bool lds_form = select_lds_full <= 160 * 1024 - 512 && ncell_dev + 1 <= kSelectMaxCands * 2;
-    if (h->device_select && h->geom.nlevels <= 16) {
+    // the grid (cell offsets + item lists) is built in the area of the selection elements, which are dead by then
+    const size_t grid_ints = h->has_grid ? (size_t)ncell_dev + 1 + (size_t)capacity : 0;
+    const bool lds_form = select_lds_full <= 160 * 1024 - 512 && grid_ints <= (size_t)kSelectMaxCands * 2;
+    if (h->device_select && h->geom.nlevels <= 16 && grid_ints <= (size_t)h->cand_cap * 2) {
         h->kp_cap = capacity;
         ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
         ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
@@ -1117,7 +1120,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
             const long half_cu = 80 * 1024 - 512;  // half of the CU's 160 KB, less the kernel's static LDS and rounding
             const long kp_area = (long)capacity * (long)(sizeof(orbx_keypoint) + sizeof(int));
             const int small_cands = (int)((half_cu - kp_area) / (long)sizeof(stdsel::Elem)) / 64 * 64;
-            const bool two_tier = small_cands >= 2048 && small_cands < kSelectMaxCands && ncell_dev + 1 <= small_cands * 2;
+            const bool two_tier = small_cands >= 2048 && small_cands < kSelectMaxCands && grid_ints <= (size_t)small_cands * 2;
             auto launch_select = [&](int max_cands, int pass) {
                 hipLaunchKernelGGL(k_select_frame<false>, dim3(n_frames), dim3(64 * h->geom.nlevels),
                                    select_lds(max_cands), h->stream, h->d_cand.p, h->cand_cap, h->d_level_counts_p,

@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     stdsel::Elem* s_el = (stdsel::Elem*)s_raw;                                  // [max_cands]
     orbx_keypoint* s_kp = (orbx_keypoint*)(s_raw + sizeof(stdsel::Elem) * max_cands);  // [kp_cap]
     int* s_cell = (int*)(s_kp + kp_cap);                                         // [kp_cap]
-    int* s_cells = (int*)s_raw;                                                  // [ncell + 1], aliases s_el later
+    int* s_cells = (int*)s_raw;                                                  // [ncell + 1] + [kp_cap] item lists, alias s_el later
     // stopper lists of the wave-parallel partitions; they alias s_kp / s_cell, which are idle during the selection
     St* s_lp = (St*)s_kp;                                                        // [max_cands]
     St* s_rp = s_lp + max_cands;                                                 // [max_cands]
@@ -1048,13 +1048,39 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     if (lvl < g.nlevels) {
         n = level_counts[b * kMaxLevels + lvl];
         for (int j = 0; j < lvl; j++) off += level_counts[b * kMaxLevels + j];
-        for (int i = lane; i < n; i += 64) s_el[off + i] = stdsel::Elem{(float)cd[off + i].score, off + i};
+    }
+    // the levels' candidates are one contiguous list: all wavefronts load it together, four loads in flight per lane
+    for (int base = 0; base < total; base += 4 * (int)blockDim.x) {
+        int sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * (int)blockDim.x + tid;
+            sc[u] = i < total ? (int)cd[i].score : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * (int)blockDim.x + tid;
+            if (i < total) s_el[i] = stdsel::Elem{(float)sc[u], i};
+        }
     }
     __syncthreads();
     if (lvl < g.nlevels) n = stdsel::wave_retain_best(s_el + off, n, 2 * g.L[lvl].quota, s_lp + off, s_rp + off, lane);
     __syncthreads();
     if (lvl < g.nlevels)
-        for (int i = lane; i < n; i += 64) s_el[off + i].key = cd[s_el[off + i].idx].harris;
+        for (int base = 0; base < n; base += 256) {   // four gathers in flight per lane
+            int ix[4];
+            float hv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + 64 * u + lane;
+                ix[u] = i < n ? s_el[off + i].idx : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) hv[u] = ix[u] >= 0 ? cd[ix[u]].harris : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ix[u] >= 0) s_el[off + base + 64 * u + lane].key = hv[u];
+        }
     __syncthreads();
     if (lvl < g.nlevels) {
         n = stdsel::wave_retain_best(s_el + off, n, g.L[lvl].quota, s_lp + off, s_rp + off, lane);
@@ -1121,53 +1147,63 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
             if (pos_y < 0 || pos_y >= gr.grid_rows || pos_x < 0 || pos_x >= gr.grid_cols) return -1;
             return pos_x * gr.grid_rows + pos_y;
         };
-        if (lvl == 0) {
-            count = compact_ordered(s_kp, count, lane, [&](const orbx_keypoint& k) { return cell_of(k) >= 0; });
-            if (lane == 0) s_cnt = count;
+        // keypoints outside the grid are dropped (ordered compaction by one wavefront) - rarely any: look first
+        int* s_items = s_cells + ncell + 1;   // [kp_cap] the cells' item lists in the order the atomics fill them
+        bool outside = false;
+        for (int i = tid; i < count; i += blockDim.x) outside |= cell_of(s_kp[i]) < 0;
+        if (__syncthreads_or(outside)) {
+            if (lvl == 0) {
+                count = compact_ordered(s_kp, count, lane, [&](const orbx_keypoint& k) { return cell_of(k) >= 0; });
+                if (lane == 0) s_cnt = count;
+            }
+            __syncthreads();
+            count = s_cnt;
         }
         for (int i = tid; i <= ncell; i += blockDim.x) s_cells[i] = 0;
         __syncthreads();
-        count = s_cnt;
         for (int i = tid; i < count; i += blockDim.x) {
             const int c = cell_of(s_kp[i]);
             s_cell[i] = c;
             atomicAdd(&s_cells[c + 1], 1);
         }
         __syncthreads();
-        if (lvl == 0) {
-            // inclusive scan of the per-cell counts by one wavefront -> CSR offsets
+        {
+            // inclusive scan of the per-cell counts -> CSR offsets: every wavefront scans one segment of the cells,
+            // then adds the totals of the segments before its own
+            const int nw = blockDim.x >> 6;
+            const int seg = ((ncell + nw - 1) / nw + 63) & ~63;
+            const int s0 = 1 + lvl * seg, s1 = min(s0 + seg, ncell + 1);
             int carry = 0;
-            for (int base = 1; base <= ncell; base += 64) {
+            for (int base = s0; base < s1; base += 64) {
                 const int i = base + lane;
-                int v = i <= ncell ? s_cells[i] : 0;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int u = __shfl_up(v, o);
-                    if (lane >= o) v += u;
-                }
-                if (i <= ncell) s_cells[i] = v + carry;
-                carry += __shfl(v, 63);
+                const int v = wave_scan_incl(i < s1 ? s_cells[i] : 0);
+                if (i < s1) s_cells[i] = v + carry;
+                carry += __builtin_amdgcn_readlane(v, 63);
             }
+            if (lane == 0) s_n[lvl] = carry;   // s_n is free again: the level counts went into s_off / s_cnt
+            __syncthreads();
+            int before = 0;
+            for (int w = 0; w < lvl; w++) before += s_n[w];
+            if (before)
+                for (int i = s0 + lane; i < s1; i += 64) s_cells[i] += before;
         }
         __syncthreads();
         int* cs = cell_start + (size_t)b * (ncell + 1);
         int* ci = cell_items + (size_t)b * kp_cap;
         for (int i = tid; i <= ncell; i += blockDim.x) cs[i] = s_cells[i];
         __syncthreads();
-        // fill: slots by atomics, then every cell's short list is put in ascending feature order (the reference
-        // appends features in index order)
-        for (int i = tid; i < count; i += blockDim.x) ci[atomicAdd(&s_cells[s_cell[i]], 1)] = i;
+        // fill: slots by atomics (s_cells[c] walks from the start of cell c to the start of cell c + 1); then every
+        // keypoint goes to the place its index has among its cell's items (the reference appends features in index
+        // order): a rank within a list of a few entries, no sorting pass over the cells
+        for (int i = tid; i < count; i += blockDim.x) s_items[atomicAdd(&s_cells[s_cell[i]], 1)] = i;
         __syncthreads();
-        for (int c = tid; c < ncell; c += blockDim.x) {
-            const int i0 = cs[c], i1 = cs[c + 1];
-            for (int i = i0 + 1; i < i1; i++) {
-                const int v = ci[i];
-                int j = i - 1;
-                while (j >= i0 && ci[j] > v) { ci[j + 1] = ci[j]; j--; }
-                ci[j + 1] = v;
-            }
+        for (int i = tid; i < count; i += blockDim.x) {
+            const int c = s_cell[i];
+            const int i0 = c ? s_cells[c - 1] : 0, i1 = s_cells[c];
+            int rank = 0;
+            for (int j = i0; j < i1; j++) rank += s_items[j] < i;
+            ci[i0 + rank] = i;
         }
-        __syncthreads();
     }
     // cv::ORB::compute -> runByImageBorder on the moved keypoints; the grid above is left as built, exactly as the
     // reference leaves it: its entries now name the slots the remaining keypoints moved into, and the last
@@ -1175,13 +1211,18 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     // those slots receive a feature no window accepts (octave -128), so the result does not depend on what an earlier
     // batch left in the buffer.
     const int pre = count;
-    if (fm.has_camera && lvl == 0) {
-        count = compact_ordered(s_kp, count, lane,
-                                [&](const orbx_keypoint& k) { return border_ok(k, fm.width, fm.height, fm.edge); });
-        if (lane == 0) s_cnt = count;
+    bool drop = false;
+    if (fm.has_camera)
+        for (int i = tid; i < count; i += blockDim.x) drop |= !border_ok(s_kp[i], fm.width, fm.height, fm.edge);
+    if (__syncthreads_or(drop)) {   // rarely any: the ordered compaction is one wavefront's work
+        if (lvl == 0) {
+            count = compact_ordered(s_kp, count, lane,
+                                    [&](const orbx_keypoint& k) { return border_ok(k, fm.width, fm.height, fm.edge); });
+            if (lane == 0) s_cnt = count;
+        }
+        __syncthreads();
+        count = s_cnt;
     }
-    __syncthreads();
-    count = s_cnt;
     orbx_keypoint* out = kps_out + (size_t)b * kp_cap;
     for (int i = tid; i < count; i += blockDim.x) out[i] = s_kp[i];
     for (int i = count + tid; i < pre; i += blockDim.x) out[i] = orbx_keypoint{0.f, 0.f, 0.f, -1.f, 0.f, -128, -1};
