@@ -216,6 +216,9 @@ def main():
                                      device=local_rank)
             self.ex.set_frame_model(cam, grid)
             self.ex.set_stream(self.tstream.cuda_stream)
+            # with one batch in flight the blur runs beside the latency-bound middle of its own batch; with several, the
+            # other batches fill those gaps and the blur runs in line
+            self.ex.set_blur_fork(max(1, args.streams) == 1)
             self.mt = orbx.Matcher(device=local_rank)
             self.mt.set_stream(self.tstream.cuda_stream)
             self.sf = self.ex.scale_tables()[1]

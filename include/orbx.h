@@ -133,6 +133,13 @@ orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera*
    tests and for frames with more candidates than the device form holds on chip. */
 orbx_status orbx_extractor_set_device_select(orbx_extractor* h, int enabled);
 
+/* No counterpart in the reference: scheduling of orbx_extract_batch.  Enabled (the default), the Gaussian blur of a
+   batch runs on a second stream of the handle beside the latency-bound kernels between FAST and the descriptors
+   (ordered emission, Harris/angle, selection): best when ONE batch is in flight on the GPU.  A caller that keeps
+   several batches in flight on handles of their own gets more from the chip with it disabled (the other batches fill
+   those gaps, and the blur then never competes with them).  Results are identical either way. */
+orbx_status orbx_extractor_set_blur_fork(orbx_extractor* h, int enabled);
+
 /* Camera::undistortPoints on n (x,y) float pairs; host arithmetic in double as cv::undistortPoints. */
 orbx_status orbx_undistort_points(const orbx_camera* camera, const float* xy_in, int n, float* xy_out);
 

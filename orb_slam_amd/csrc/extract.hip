@@ -35,6 +35,7 @@ struct orbx_extractor {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_pyramid = nullptr, ev_blur = nullptr;
     bool blur_forked = false;
+    bool fork_blur = true;   // orbx_extract_batch runs the blur on the side stream beside emission / Harris / selection
 
     // geometry of the current image size
     int cur_w = -1, cur_h = -1, cur_levels = -1;
@@ -1046,7 +1047,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(ensure_buffers(h, n_frames));
     h->last_frames = n_frames;
     BlurForkGuard fork_guard{h};  // whichever way this call ends, the side stream is joined
-    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, true));
+    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, h->fork_blur));
 
     // Device-resident path: selection, undistortion, bucket grid and border filter run in one kernel per frame
     // (k_select_frame), so nothing crosses PCIe between detect and compute.  Its fast form keeps a frame's candidates
@@ -1237,6 +1238,12 @@ orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redon
         return ORBX_OK;
     }
     return batch_host_path(h, a.n_frames, a.width, a.height, a.capacity, nullptr, counts, nullptr);
+}
+
+orbx_status orbx_extractor_set_blur_fork(orbx_extractor* h, int enabled) {
+    if (!h) return ORBX_BAD_ARG;
+    h->fork_blur = enabled != 0;
+    return ORBX_OK;
 }
 
 orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera* camera, const orbx_grid* grid) {

@@ -32,7 +32,7 @@ SYMBOLS = [
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
-    "orbx_extractor_set_device_select", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+    "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
 ]
 
 
@@ -226,6 +226,10 @@ class Extractor:
         redone = C.c_int(0)
         _check(lib().orbx_extractor_finish(self._h, _p(counts), C.byref(redone)), "orbx_extractor_finish")
         return counts, bool(redone.value)
+
+    def set_blur_fork(self, enabled):
+        """Blur of a batch on the handle's side stream (default) or in line (several batches in flight)."""
+        _check(lib().orbx_extractor_set_blur_fork(self._h, int(bool(enabled))), "orbx_extractor_set_blur_fork")
 
     def set_image_cache(self, enabled):
         _check(lib().orbx_extractor_set_image_cache(self._h, int(enabled)), "orbx_extractor_set_image_cache")

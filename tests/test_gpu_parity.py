@@ -172,6 +172,28 @@ def test_compute_reuses_the_pyramid_of_detect(oracle, test_images):
     ex.close()
 
 
+def test_blur_in_line_equals_blur_on_the_side_stream(test_images):
+    """orbx_extractor_set_blur_fork only changes when the blur runs: keypoints, descriptors and grid of a batch are the
+    same bits with it on the side stream (default) and in line."""
+    import torch
+    frames = [test_images[0], test_images[1], np.ascontiguousarray(test_images[0][::-1])]
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    out = []
+    for fork in (True, False, True):
+        ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(frames))
+        ex.set_blur_fork(fork)
+        for _ in range(2):   # twice on the same handle: the second call starts while nothing of the first is pending
+            kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1280)
+        out.append((kps.copy(), counts.copy(), desc.copy()))
+        ex.close()
+    for kps, counts, desc in out[1:]:
+        assert np.array_equal(counts, out[0][1])
+        for f in range(len(frames)):
+            n = counts[f]
+            assert np.array_equal(kps[f, :n], out[0][0][f, :n]) and np.array_equal(desc[f, :n], out[0][2][f, :n])
+
+
 def test_deferred_batch_and_finish(oracle, test_images):
     """orbx_extract_batch without host outputs returns with the work queued; orbx_extractor_finish reports the counts
     and the status.  Same device results as the synchronous call; a frame with more candidates than the on-device
