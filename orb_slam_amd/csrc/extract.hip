@@ -445,7 +445,8 @@ void run_emit_and_harris(orbx_extractor* h, int frames) {
     {
         const int chunks = frames >= 64 ? 32 : 256;
         hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
-                           h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax, h->harris_scale_sq_sq,
+                           h->d_cand.p, (const uint4*)h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax,
+                           h->harris_scale_sq_sq,
                            chunks, frames);
     }
     T.end(ST_HARRIS, s);

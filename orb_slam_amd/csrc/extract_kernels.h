@@ -810,8 +810,11 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // retainBest(2*quota) value are skipped: cv::ORB has dropped them before it computes either quantity.
 // Harris: lane = one pixel of the block, three 4-byte row loads.  Angle: lane = half a patch row, four 4-byte loads,
 // byte sums and |u|-weighted byte sums by dot products (all integer, so the summation order does not matter).
+// cand_ro is the candidate array again, read-only: position, score and level of a record never change here (only its
+// response and angle are written), so the records can be fetched through the scalar path.
 __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
-                                                      Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
+                                                      Cand* __restrict__ cand, const uint4* __restrict__ cand_ro,
+                                                      int cap, const int* __restrict__ totals,
                                                       const int* __restrict__ thresholds, UMax umax,
                                                       float scale_sq_sq, int chunks, int frames) {
     // per wavefront: the five sums and the index of up to 64 reduced candidates, finished 64 at a time (below)
@@ -849,25 +852,31 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
     // dependent loads (candidate -> pixels), so it runs as a software pipeline: the candidate record two steps
     // ahead and the pixels one step ahead are in flight while the current candidate is reduced.
     const int stride = chunks * 4;
-    const int idx0 = chunk * 4 + (int)(threadIdx.x >> 6);
+    const int idx0 = chunk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int thr_l = lane < kMaxLevels ? thresholds[b * kMaxLevels + lane] : 0;
     Cand* cbase = cand + (size_t)b * cap;
+    const uint4* cro = cand_ro + (size_t)b * cap;
     const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
+    // per-lane offsets of the four loads from the candidate's centre pixel (an atlas is far smaller than 4 GB: the
+    // frame base stays a scalar pair and the lane offset a single 32-bit register)
+    const int hofs0 = h_ofs - aw, hofs2 = h_ofs + aw;
+    // a candidate record is the same for all lanes: its index is wavefront-uniform, so it is read once per wavefront
+    auto record = [&](int i) { return cro[min(i, max(total - 1, 0))]; };
     struct Px { unsigned r0, r1, r2; uint4 q; bool live; };
-    auto fetch_px = [&](const Cand& c, bool valid) {
+    auto fetch_px = [&](const uint4& rec, bool valid) {
         Px p;
         p.r0 = p.r1 = p.r2 = 0u;
         p.q = make_uint4(0u, 0u, 0u, 0u);
-        const int lvl = __builtin_amdgcn_readfirstlane((int)c.level) & (kMaxLevels - 1);
-        p.live = valid && (int)c.score >= __builtin_amdgcn_readlane(thr_l, lvl);
+        const unsigned xy = __builtin_amdgcn_readfirstlane(rec.x), sl = __builtin_amdgcn_readfirstlane(rec.y);
+        const int lvl = (int)((sl >> 8) & (kMaxLevels - 1));
+        p.live = valid && (int)(sl & 0xffu) >= __builtin_amdgcn_readlane(thr_l, lvl);
         if (p.live) {
             const LevelInfo L = g.L[lvl];
-            const uint8_t* center = fb + (size_t)(L.y + c.y) * aw + L.x + c.x;
-            const uint8_t* hp = center + h_ofs;
-            p.r0 = load_u32_any(hp - aw);
-            p.r1 = load_u32_any(hp);
-            p.r2 = load_u32_any(hp + aw);
-            p.q = load_u128_any(center + row_ofs);
+            const int cofs = (L.y + (int)(xy >> 16)) * aw + L.x + (int)(xy & 0xffffu);
+            p.r0 = load_u32_any(fb + (unsigned)(cofs + hofs0));
+            p.r1 = load_u32_any(fb + (unsigned)(cofs + h_ofs));
+            p.r2 = load_u32_any(fb + (unsigned)(cofs + hofs2));
+            p.q = load_u128_any(fb + (unsigned)(cofs + row_ofs));
         }
         return p;
     };
@@ -898,57 +907,59 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
         n_res = 0;
     };
     const bool odd = lane & 1, upper = lane & 2;
-    Cand c_cur = cbase[min(idx0, max(total - 1, 0))];
-    Cand c_nxt = cbase[min(idx0 + stride, max(total - 1, 0))];
-    Px px_cur = fetch_px(c_cur, idx0 < total);
-    for (int idx = idx0; idx < total; idx += stride) {
-        const Cand c_nn = cbase[min(idx + 2 * stride, total - 1)];
-        const Px px_nxt = fetch_px(c_nxt, idx + stride < total);
-        if (px_cur.live) {
-            const unsigned r0 = px_cur.r0, r1 = px_cur.r1, r2 = px_cur.r2;
-            const unsigned q[4] = {px_cur.q.x, px_cur.q.y, px_cur.q.z, px_cur.q.w};
-            int ha = 0, hb = 0, hc = 0;
-            if (lane < 49) {
-                const int a0 = r0 & 255, a1 = (r0 >> 8) & 255, a2 = (r0 >> 16) & 255;
-                const int b0 = r1 & 255, b2 = (r1 >> 16) & 255;
-                const int c0 = r2 & 255, c1 = (r2 >> 8) & 255, c2 = (r2 >> 16) & 255;
-                const int Ix = (b2 - b0) * 2 + (a2 - a0) + (c2 - c0);
-                const int Iy = (c1 - a1) * 2 + (c0 - a0) + (c2 - a2);
-                ha = Ix * Ix;
-                hb = Iy * Iy;
-                hc = Ix * Iy;
-            }
-            unsigned ssum = 0, wsum = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned m = q[j] & msk[j];
-                ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
-                wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
-            }
-            // Five sums over the wavefront at the price of about two.  Two exchanges inside each quad of lanes fold
-            // four of them into ONE register (lane & 3 = 0: sum Ix^2, 1: sum Iy^2, 2: sum IxIy, 3: m10 - each lane
-            // keeps the quantity of its class and hands the other one to its partner), two row shifts by 4 and 8 leave
-            // every row's class totals in its lanes 12..15, and those 16 lanes add them into the parked record in LDS.
-            // m01 takes the same steps in a register of its own.  All integer: the order of summation is free.
-            const int w10 = right ? (int)wsum : -(int)wsum, w01 = v * (int)ssum;
-            const int x1 = (odd ? hb : ha) + __builtin_amdgcn_update_dpp(0, odd ? ha : hb, 0xB1, 0xF, 0xF, false);
-            const int x2 = (odd ? w10 : hc) + __builtin_amdgcn_update_dpp(0, odd ? hc : w10, 0xB1, 0xF, 0xF, false);
-            int y = w01 + __builtin_amdgcn_update_dpp(0, w01, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-            int z = (upper ? x2 : x1) + __builtin_amdgcn_update_dpp(0, upper ? x1 : x2, 0x4E, 0xF, 0xF, false);
-            y += __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xF, 0xF, false);                  // quad_perm [2,3,0,1]
-            z += __builtin_amdgcn_update_dpp(0, z, 0x114, 0xF, 0xF, true);                  // row_shr:4, zeros shifted in
-            y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
-            z += __builtin_amdgcn_update_dpp(0, z, 0x118, 0xF, 0xF, true);                  // row_shr:8
-            y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
-            if ((lane & 12) == 12) atomicAdd(&res[n_res][lane & 3], z);
-            if ((lane & 15) == 15) atomicAdd(&res[n_res][4], y);
-            if (lane == 63) res[n_res][5] = idx;
-            n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
-            if (n_res == 64) finish();
+    auto process = [&](const Px& px, int idx) {
+        if (!px.live) return;
+        const unsigned r0 = px.r0, r1 = px.r1, r2 = px.r2;
+        const unsigned q[4] = {px.q.x, px.q.y, px.q.z, px.q.w};
+        int ha = 0, hb = 0, hc = 0;
+        if (lane < 49) {
+            const int a0 = r0 & 255, a1 = (r0 >> 8) & 255, a2 = (r0 >> 16) & 255;
+            const int b0 = r1 & 255, b2 = (r1 >> 16) & 255;
+            const int c0 = r2 & 255, c1 = (r2 >> 8) & 255, c2 = (r2 >> 16) & 255;
+            const int Ix = (b2 - b0) * 2 + (a2 - a0) + (c2 - c0);
+            const int Iy = (c1 - a1) * 2 + (c0 - a0) + (c2 - a2);
+            ha = Ix * Ix;
+            hb = Iy * Iy;
+            hc = Ix * Iy;
         }
-        c_cur = c_nxt;
-        c_nxt = c_nn;
-        px_cur = px_nxt;
+        unsigned ssum = 0, wsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned m = q[j] & msk[j];
+            ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
+            wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
+        }
+        // Five sums over the wavefront at the price of about two.  Two exchanges inside each quad of lanes fold
+        // four of them into ONE register (lane & 3 = 0: sum Ix^2, 1: sum Iy^2, 2: sum IxIy, 3: m10 - each lane
+        // keeps the quantity of its class and hands the other one to its partner), two row shifts by 4 and 8 leave
+        // every row's class totals in its lanes 12..15, and those 16 lanes add them into the parked record in LDS.
+        // m01 takes the same steps in a register of its own.  All integer: the order of summation is free.
+        const int w10 = right ? (int)wsum : -(int)wsum, w01 = v * (int)ssum;
+        const int x1 = (odd ? hb : ha) + __builtin_amdgcn_update_dpp(0, odd ? ha : hb, 0xB1, 0xF, 0xF, false);
+        const int x2 = (odd ? w10 : hc) + __builtin_amdgcn_update_dpp(0, odd ? hc : w10, 0xB1, 0xF, 0xF, false);
+        int y = w01 + __builtin_amdgcn_update_dpp(0, w01, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        int z = (upper ? x2 : x1) + __builtin_amdgcn_update_dpp(0, upper ? x1 : x2, 0x4E, 0xF, 0xF, false);
+        y += __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xF, 0xF, false);                  // quad_perm [2,3,0,1]
+        z += __builtin_amdgcn_update_dpp(0, z, 0x114, 0xF, 0xF, true);                  // row_shr:4, zeros shifted in
+        y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
+        z += __builtin_amdgcn_update_dpp(0, z, 0x118, 0xF, 0xF, true);                  // row_shr:8
+        y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
+        if ((lane & 12) == 12) atomicAdd(&res[n_res][lane & 3], z);
+        if ((lane & 15) == 15) atomicAdd(&res[n_res][4], y);
+        if (lane == 63) res[n_res][5] = idx;
+        n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
+        if (n_res == 64) finish();
+    };
+    // two candidates per trip, in two sets of registers that take turns (no copies from "next" to "current")
+    uint4 rec_a = record(idx0), rec_b = record(idx0 + stride);
+    Px px_a = fetch_px(rec_a, idx0 < total);
+    for (int idx = idx0; idx < total; idx += 2 * stride) {
+        rec_a = record(idx + 2 * stride);
+        const Px px_b = fetch_px(rec_b, idx + stride < total);
+        process(px_a, idx);
+        rec_b = record(idx + 3 * stride);
+        px_a = fetch_px(rec_a, idx + 2 * stride < total);
+        process(px_b, idx + stride);
     }
     if (n_res > 0) finish();
 }
