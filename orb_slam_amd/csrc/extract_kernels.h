@@ -1437,14 +1437,16 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
     const int q[8] = {(int)qa.x, (int)qa.y, (int)qa.z, (int)qa.w, (int)qb.x, (int)qb.y, (int)qb.z, (int)qb.w};
     const bool staged = cx - kBriefR >= 0 && cx + kBriefR + 1 < lw && cy - kBriefR >= 0 && cy + kBriefR < lh;
     if (staged) {
-        const uint8_t* corner = blurred + org + (ptrdiff_t)(cy - kBriefR) * aw + (cx - kBriefR);
+        // uniform frame base + one 32-bit offset per lane (an atlas is far smaller than 4 GB)
+        const uint8_t* fbb = blurred + (size_t)b * atlas_bytes;
+        const unsigned corner = (unsigned)((int)s1.x + (cy - kBriefR) * aw + (cx - kBriefR));
         constexpr int kDwords = kBriefRows * (kBriefPitch / 4), kSteps = (kDwords + 31) / 32;
         unsigned tmp[kSteps];
 #pragma unroll
         for (int k = 0; k < kSteps; k++) {  // all row loads in flight, then the LDS stores
             const int i = min(lane + 32 * k, kDwords - 1);
-            const int r = i / (kBriefPitch / 4), c = i - r * (kBriefPitch / 4);
-            tmp[k] = load_u32_any(corner + (__umul24((unsigned)r, (unsigned)aw) + 4u * (unsigned)c));
+            const int r = div_small<kBriefPitch / 4>(i), c = i - r * (kBriefPitch / 4);
+            tmp[k] = load_u32_any(fbb + (corner + __umul24((unsigned)r, (unsigned)aw) + 4u * (unsigned)c));
         }
 #pragma unroll
         for (int k = 0; k < kSteps; k++)
