@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void k_bf_sad_radius(const uint8_t* __restrict
 
 struct ProjArgs {
     orbx_grid g;
+    unsigned gx_magic, gy_magic;  // ceil(2^32 / grid_size_x), ceil(2^32 / grid_size_y): see div_cell (0 when the size is 1)
     // per-frame arrays; the single-pair entry points use stride 0 and no index arrays
     const int32_t* frame_index;  // [pairs] or NULL (frame 0)
     const int32_t* ref_index;    // [pairs] or NULL (reference 0)
@@ -270,9 +271,26 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 
 struct Window {
     float px, py, radius_scaled;
-    int min_level, max_level, left, up, ncy, ncells;
+    int min_level, max_level, left, up, ncx, ncy, ncells;
     bool min_only;
 };
+
+// num / d as C divides (towards zero), for the cell arithmetic of getBoxAroundPoint (frame.cpp:89-118): d is a grid
+// cell size, the same for every lane, and magic = ceil(2^32 / d).  floor(a * magic / 2^32) = floor(a / d) while
+// a * d < 2^32, so numerators below 2^20 and sizes below 2^11 take one multiply-high instead of a division routine.
+__device__ __forceinline__ int div_cell(int num, int d, unsigned magic) {
+    const unsigned a = (unsigned)(num < 0 ? -num : num);
+    int q;
+    if (__builtin_expect(a < (1u << 20) && d > 1 && d < (1 << 11), 1)) q = (int)__umulhi(a, magic);
+    else q = (int)(a / (unsigned)d);
+    return num < 0 ? -q : q;
+}
+
+inline void set_grid(ProjArgs& A, const orbx_grid* g) {
+    A.g = *g;
+    A.gx_magic = g->grid_size_x > 1 ? (unsigned)((0x100000000ull + (unsigned)g->grid_size_x - 1) / (unsigned)g->grid_size_x) : 0u;
+    A.gy_magic = g->grid_size_y > 1 ? (unsigned)((0x100000000ull + (unsigned)g->grid_size_y - 1) / (unsigned)g->grid_size_y) : 0u;
+}
 
 // Points A's per-frame / per-pair views at pair `pair`.
 __device__ __forceinline__ void resolve_views(ProjArgs& A, int pair) {
@@ -334,16 +352,17 @@ __device__ __forceinline__ bool window_of(const ProjArgs& A, int ref_idx, Window
         W.min_level = level - 1;
         W.max_level = level;
     }
-    W.left = max(0, (int)floorf(W.px - g.min_x - W.radius_scaled) / g.grid_size_x);
+    W.left = max(0, div_cell((int)floorf(W.px - g.min_x - W.radius_scaled), g.grid_size_x, A.gx_magic));
     if (W.left >= g.grid_cols) return false;
-    const int right = min(g.grid_cols - 1, (int)ceilf(W.px - g.min_x + W.radius_scaled) / g.grid_size_x);
+    const int right = min(g.grid_cols - 1, div_cell((int)ceilf(W.px - g.min_x + W.radius_scaled), g.grid_size_x, A.gx_magic));
     if (right < 0) return false;
-    W.up = max(0, (int)floorf(W.py - g.min_y - W.radius_scaled) / g.grid_size_y);
+    W.up = max(0, div_cell((int)floorf(W.py - g.min_y - W.radius_scaled), g.grid_size_y, A.gy_magic));
     if (W.up >= g.grid_rows) return false;
-    const int down = min(g.grid_rows - 1, (int)ceilf(W.py - g.min_y + W.radius_scaled) / g.grid_size_y);
+    const int down = min(g.grid_rows - 1, div_cell((int)ceilf(W.py - g.min_y + W.radius_scaled), g.grid_size_y, A.gy_magic));
     if (down < 0) return false;
+    W.ncx = right - W.left + 1;
     W.ncy = down - W.up + 1;
-    W.ncells = (right - W.left + 1) * W.ncy;
+    W.ncells = W.ncx * W.ncy;
     return true;
 }
 
@@ -903,7 +922,7 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
     }
     const uint4* rdp = (const uint4*)(A.ref_desc + (size_t)ref_idx * 32);
     const uint4 ra = rdp[0], rb = rdp[1];
-    const int ncols = W.ncells / W.ncy;
+    const int ncols = W.ncx;
     int list_n = 0;
     for (int cb = 0; cb < ncols && list_n <= kSortK; cb += 16) {
         int start = 0, len = 0;
@@ -1803,7 +1822,7 @@ static orbx_status run_projection(orbx_matcher* h, int mode, const orbx_grid* g,
 
     ProjArgs A;
     std::memset(&A, 0, sizeof(A));
-    A.g = *g;
+    set_grid(A, g);
     A.cell_start = h->d_cells.p;
     A.cell_items = h->d_items.p;
     A.kps = h->d_kp.p;
@@ -1897,7 +1916,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     ORBX_HIP(hipMemsetAsync(h->d_ints.p, 0, sizeof(int32_t) * n_pairs, s));
     ProjArgs A;
     std::memset(&A, 0, sizeof(A));
-    A.g = *g;
+    set_grid(A, g);
     A.frame_index = d_frame_index;
     A.ref_index = d_ref_index;
     A.counts = d_counts;
@@ -1988,7 +2007,7 @@ orbx_status orbx_match_projection_points_batch(orbx_matcher* h, const orbx_grid*
     ORBX_HIP(hipMemsetAsync(h->d_ints.p, 0, sizeof(int32_t) * n_pairs, s));
     ProjArgs A;
     std::memset(&A, 0, sizeof(A));
-    A.g = *g;
+    set_grid(A, g);
     A.frame_index = d_frame_index;
     A.counts = d_counts;
     A.kp_stride = kp_capacity;
