@@ -402,6 +402,8 @@ __device__ __forceinline__ int div_small(int i) {
 
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ short2v as_short2v(unsigned w) { return __builtin_bit_cast(short2v, w); }
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ushort2v as_ushort2v(unsigned w) { return __builtin_bit_cast(ushort2v, w); }
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ atlas, uint8_t* __restrict__ score,
@@ -486,24 +488,30 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12), one of {0, 8} and
             // one of {4, 12}: a corner needs min(max(p0, p8), max(p4, p12)) above the band or
             // max(min(p0, p8), min(p4, p12)) below it.  Both sides fold into ONE compare per pixel, so the scalar unit
-            // (one per CU, shared by the four SIMDs) only counts bits.  Lanes without a row carry a threshold nothing
-            // reaches; columns outside the scored range are dropped when the queue is read (phase 2).
-            const int thr = valid ? threshold : 1024;
-            // two pixels per instruction: even pixels of the dword in one pair of 16-bit halves, odd pixels in another
+            // (one per CU, shared by the four SIMDs) only counts bits.  Columns outside the scored range are dropped
+            // when the queue is read (phase 2).
+            // Two pixels per instruction, without unpacking: one AND leaves the even bytes of a dword as two 16-bit
+            // values, another the odd bytes as two 16-bit values times 256.  Unsigned packed min / max order both forms
+            // alike, a saturating subtract keeps max(difference, 0) - all the compare against a threshold >= 0 needs -
+            // and the odd pixels are compared against the threshold times 256.
             unsigned long long pass[4];
             bool mine[4];
             int total = 0;
 #pragma unroll
             for (int hsel = 0; hsel < 2; hsel++) {
-                const unsigned sel = hsel ? 0x0c030c01u : 0x0c020c00u;
-                const short2v v = as_short2v(__builtin_amdgcn_perm(0u, C, sel));
-                const short2v p0 = as_short2v(__builtin_amdgcn_perm(0u, P0, sel)), p4 = as_short2v(__builtin_amdgcn_perm(0u, P4, sel));
-                const short2v p8 = as_short2v(__builtin_amdgcn_perm(0u, P8, sel)), p12 = as_short2v(__builtin_amdgcn_perm(0u, P12, sel));
-                const short2v up = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)) - v;
-                const short2v dn = v - __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
-                const short2v m = __builtin_elementwise_max(up, dn);
-                mine[hsel] = m.x > (short)thr;
-                mine[hsel + 2] = m.y > (short)thr;
+                const unsigned keep = hsel ? 0xff00ff00u : 0x00ff00ffu;
+                const ushort2v v = as_ushort2v(C & keep);
+                const ushort2v p0 = as_ushort2v(P0 & keep), p4 = as_ushort2v(P4 & keep);
+                const ushort2v p8 = as_ushort2v(P8 & keep), p12 = as_ushort2v(P12 & keep);
+                const ushort2v up = __builtin_elementwise_sub_sat(
+                    __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12)), v);
+                const ushort2v dn = __builtin_elementwise_sub_sat(
+                    v, __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12)));
+                const ushort2v m = __builtin_elementwise_max(up, dn);
+                // lanes without a row carry a threshold nothing reaches
+                const unsigned thr16 = valid ? (unsigned)(hsel ? threshold << 8 : threshold) : 0xffffu;
+                mine[hsel] = (unsigned)m.x > thr16;
+                mine[hsel + 2] = (unsigned)m.y > thr16;
                 pass[hsel] = __ballot(mine[hsel]);
                 pass[hsel + 2] = __ballot(mine[hsel + 2]);
                 total += __popcll(pass[hsel]) + __popcll(pass[hsel + 2]);
