@@ -403,6 +403,7 @@ __device__ __forceinline__ int div_small(int i) {
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ short2v as_short2v(unsigned w) { return __builtin_bit_cast(short2v, w); }
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ushort2v as_ushort2v(unsigned w) { return __builtin_bit_cast(ushort2v, w); }
 
 template <bool DENSE>
@@ -546,28 +547,47 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
         wq[q] = (unsigned short)pos;
         const uint8_t* ctr = t + __mul24(r + 3, kFPitch) + c + 3 + off;
         const int v = ctr[0];
-        // A pair of 16-bit halves (p, -p) per ring pixel p, made by ONE 24-bit multiply: p * -65535 = p - (p << 16).
-        // The minimum of the low halves over an arc of nine is the arc's darkest pixel and of the high halves minus its
-        // brightest one, so one packed minimum tree serves both sides, and the centre value enters only at the end:
+        // Ring pixels as half-precision numbers, two per register: 0x6400 | p is 1024 + p exactly, so floating-point
+        // minima and maxima order them like the bytes, and gfx950 has a packed three-operand form of both
+        // (v_pk_minimum3_f16 / v_pk_maximum3_f16: four comparisons per instruction).  Register j holds ring positions
+        // (j, j + 8); position j + 8 .. j + 15 is the same register with its halves swapped, which the instruction's
+        // operand selectors do for free.  m3[j]: minima over 3 consecutive positions from j (and from j + 8);
+        // m9 = min3(m3[j], m3[j + 3], m3[j + 6]): the arc of nine from j (and from j + 8).
         // bright margin = max over arcs of (min p) - v, dark margin = v - min over arcs of (max p).
-        // m2/m4/m8: minima over 2, 4, 8 consecutive ring positions starting at k; m9 adds the ninth.
-        short2v P[16], m2[16], m4[16];
+        half2v Q[16], lo3[16], hi3[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int r8 = ctr[dy[k] * kFPitch + dx[k]];
-            P[k] = as_short2v((unsigned)__mul24(r8, -65535));
+        for (int k = 0; k < 8; k++) {
+            const unsigned ra = ctr[dy[k] * kFPitch + dx[k]], rb = ctr[dy[k + 8] * kFPitch + dx[k + 8]];
+            Q[k] = __builtin_bit_cast(half2v, ra | (rb << 16) | 0x64006400u);
+            Q[k + 8] = Q[k].yx;
         }
 #pragma unroll
-        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(P[k], P[(k + 1) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
-        short2v acc = {(short)-32768, (short)-32768};
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const short2v m8 = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-            acc = __builtin_elementwise_max(acc, __builtin_elementwise_min(m8, P[(k + 8) & 15]));
+        for (int k = 0; k < 8; k++) {
+            lo3[k] = __builtin_elementwise_minimum(__builtin_elementwise_minimum(Q[k], Q[k + 1]), Q[k + 2]);
+            hi3[k] = __builtin_elementwise_maximum(__builtin_elementwise_maximum(Q[k], Q[k + 1]), Q[k + 2]);
+            lo3[k + 8] = lo3[k].yx;
+            hi3[k + 8] = hi3[k].yx;
         }
-        const int best = max(threshold, max((int)acc.x - v, (int)acc.y + v));
+        half2v lo9[8], hi9[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            lo9[k] = __builtin_elementwise_minimum(__builtin_elementwise_minimum(lo3[k], lo3[k + 3]), lo3[k + 6]);
+            hi9[k] = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hi3[k], hi3[k + 3]), hi3[k + 6]);
+        }
+        half2v up = __builtin_elementwise_maximum(lo9[6], lo9[7]), dn = __builtin_elementwise_minimum(hi9[6], hi9[7]);
+#pragma unroll
+        for (int k = 0; k < 6; k += 3) {
+            up = __builtin_elementwise_maximum(__builtin_elementwise_maximum(lo9[k], lo9[k + 1]),
+                                               __builtin_elementwise_maximum(lo9[k + 2], up));
+            dn = __builtin_elementwise_minimum(__builtin_elementwise_minimum(hi9[k], hi9[k + 1]),
+                                               __builtin_elementwise_minimum(hi9[k + 2], dn));
+        }
+        up = __builtin_elementwise_maximum(up, up.yx);
+        dn = __builtin_elementwise_minimum(dn, dn.yx);
+        // the low byte of 0x6400 | p is p again
+        const int brightest_min = (int)(__builtin_bit_cast(unsigned, up) & 0xffu);
+        const int darkest_max = (int)(__builtin_bit_cast(unsigned, dn) & 0xffu);
+        const int best = max(threshold, max(brightest_min - v, v - darkest_max));
         if (best > threshold) st[pos] = (uint8_t)(best - 1);  // an arc of nine clears the band <=> a corner
     }
     __syncthreads();

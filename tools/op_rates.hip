@@ -167,6 +167,50 @@ __global__ __launch_bounds__(256) void k_min_u32_dpp(unsigned* out, unsigned c, 
     for (int i = 0; i < iters; i++) { R16(asm volatile("v_min_u32_dpp %0, %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %1, %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %2, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %3, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(c) : "vcc");) }
     if ((x0 ^ x1 ^ x2 ^ x3) == 0x12345u) out[0] = x0;
 }
+
+// Three-operand and packed floating-point minima / maxima (pixel values are exact in f16 and f32).
+#define RATE_KERNEL3(NAME, OP) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned c, int iters) { \
+    unsigned x0 = threadIdx.x | 0x64006400u, x1 = 0x64016401u, x2 = 0x64026402u, x3 = 0x64036403u; \
+    for (int i = 0; i < iters; i++) { R16(asm volatile(OP " %0, %0, %4, %4\n " OP " %1, %1, %4, %4\n " OP " %2, %2, %4, %4\n " OP " %3, %3, %4, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(c) : "vcc");) } \
+    if ((x0 ^ x1 ^ x2 ^ x3) == 0x12345u) out[0] = x0; \
+}
+#define RATE_KERNEL2(NAME, OP) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned c, int iters) { \
+    unsigned x0 = threadIdx.x | 0x64006400u, x1 = 0x64016401u, x2 = 0x64026402u, x3 = 0x64036403u; \
+    for (int i = 0; i < iters; i++) { R16(asm volatile(OP " %0, %0, %4\n " OP " %1, %1, %4\n " OP " %2, %2, %4\n " OP " %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(c) : "vcc");) } \
+    if ((x0 ^ x1 ^ x2 ^ x3) == 0x12345u) out[0] = x0; \
+}
+#define RATE_KERNEL1(NAME, OP) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned c, int iters) { \
+    unsigned x0 = threadIdx.x | 0x64006400u, x1 = 0x64016401u, x2 = 0x64026402u, x3 = 0x64036403u; \
+    for (int i = 0; i < iters; i++) { R16(asm volatile(OP " %0, %0\n " OP " %1, %1\n " OP " %2, %2\n " OP " %3, %3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(c) : "vcc");) } \
+    if ((x0 ^ x1 ^ x2 ^ x3) == 0x12345u) out[0] = x0; \
+}
+RATE_KERNEL3(k_pk_minimum3_f16, "v_pk_minimum3_f16")
+RATE_KERNEL3(k_pk_maximum3_f16, "v_pk_maximum3_f16")
+RATE_KERNEL2(k_pk_min_f16, "v_pk_min_f16")
+RATE_KERNEL2(k_pk_max_f16, "v_pk_max_f16")
+RATE_KERNEL2(k_pk_add_f16, "v_pk_add_f16")
+RATE_KERNEL3(k_min3_f16, "v_min3_f16")
+RATE_KERNEL3(k_min3_f32, "v_min3_f32")
+RATE_KERNEL3(k_max3_f32, "v_max3_f32")
+RATE_KERNEL3(k_minimum3_f32, "v_minimum3_f32")
+RATE_KERNEL3(k_min3_i16, "v_min3_i16")
+RATE_KERNEL3(k_min3_u16, "v_min3_u16")
+RATE_KERNEL3(k_max3_i16, "v_max3_i16")
+RATE_KERNEL2(k_min_f32, "v_min_f32")
+RATE_KERNEL2(k_max_f32, "v_max_f32")
+RATE_KERNEL2(k_max_f16, "v_max_f16")
+RATE_KERNEL1(k_cvt_f32_ubyte0, "v_cvt_f32_ubyte0")
+RATE_KERNEL1(k_cvt_f32_ubyte3, "v_cvt_f32_ubyte3")
+RATE_KERNEL2(k_pk_min_u16, "v_pk_min_u16")
+RATE_KERNEL2(k_pk_sub_u16_clamp, "v_pk_sub_u16")
+RATE_KERNEL3(k_perm, "v_perm_b32")
+RATE_KERNEL3(k_bfi, "v_bfi_b32")
+RATE_KERNEL3(k_or3, "v_or3_b32")
+RATE_KERNEL3(k_xad, "v_xad_u32")
+RATE_KERNEL3(k_add3, "v_add3_u32")
 template <typename K> void run(const char* name, K kern, unsigned* d) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int blocks = 256 * 8, iters = 1024;
@@ -214,4 +258,28 @@ int main() { unsigned* d; (void)hipMalloc(&d, 64);
     run("sad_u8_sdwa_min", k_sad_u8_sdwa_min, d);
     run("add_sdwa", k_add_sdwa, d);
     run("min_u32_dpp", k_min_u32_dpp, d);
+    run("pk_minimum3_f16", k_pk_minimum3_f16, d);
+    run("pk_maximum3_f16", k_pk_maximum3_f16, d);
+    run("pk_min_f16", k_pk_min_f16, d);
+    run("pk_max_f16", k_pk_max_f16, d);
+    run("pk_add_f16", k_pk_add_f16, d);
+    run("min3_f16", k_min3_f16, d);
+    run("min3_f32", k_min3_f32, d);
+    run("max3_f32", k_max3_f32, d);
+    run("minimum3_f32", k_minimum3_f32, d);
+    run("min3_i16", k_min3_i16, d);
+    run("min3_u16", k_min3_u16, d);
+    run("max3_i16", k_max3_i16, d);
+    run("min_f32", k_min_f32, d);
+    run("max_f32", k_max_f32, d);
+    run("max_f16", k_max_f16, d);
+    run("cvt_f32_ubyte0", k_cvt_f32_ubyte0, d);
+    run("cvt_f32_ubyte3", k_cvt_f32_ubyte3, d);
+    run("pk_min_u16", k_pk_min_u16, d);
+    run("pk_sub_u16", k_pk_sub_u16_clamp, d);
+    run("perm", k_perm, d);
+    run("bfi", k_bfi, d);
+    run("or3", k_or3, d);
+    run("xad", k_xad, d);
+    run("add3", k_add3, d);
     return 0; }
