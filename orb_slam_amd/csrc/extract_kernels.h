@@ -414,6 +414,9 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     __shared__ __align__(16) unsigned t32[kFRows * kFPitch / 4];
     __shared__ unsigned s32[(kSW * kSH + 3) / 4];
     __shared__ unsigned short queue[kQTotal];
+    // a patch of equal pixels for the lanes of a pass that have no row: every read of the compass test (the centre
+    // dword, its two neighbours, three rows up and down) finds zeros there, and equal pixels never pass
+    __shared__ unsigned s_flat[2 * 3 * (kFPitch / 4) + 4];
     // the row masks and their packed scores are first needed in phase 3, when the staged pixels are dead: they share
     // the staging buffer, which brings a tile's LDS under 20 KB - eight tiles per CU instead of seven
     unsigned* s_mask = t32;
@@ -465,6 +468,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
             if (tid + 256 * k < kSegs) ((uint4*)t32)[tid + 256 * k] = tmp[k];
     }
     for (int i = tid; i < (kSW * kSH + 3) / 4; i += 256) s32[i] = 0u;
+    if (tid < 2 * 3 * (kFPitch / 4) + 4) s_flat[tid] = 0u;
     __syncthreads();
     constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
@@ -475,32 +479,37 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
     {
         const int nrows = empty ? 0 : ye - ys;
         const int r0 = div_small<kFGroups>(tid), gq = tid - __mul24(r0, kFGroups);
-        const bool in_pass = r0 < kFPassRows;
-        const unsigned* tr = t32 + __mul24(ys - tl.y0 + 4 + r0, kFPitch / 4) + gq;
+        // rows this lane still has when a pass starts at row rb: rows_left > rb (none for the threads beyond the
+        // last whole row of dwords)
+        const int rows_left = r0 < kFPassRows ? nrows - r0 : 0;
+        // all five reads of a lane sit at non-negative offsets from one address: three rows up and one dword left
+        constexpr int kUp = 3 * (kFPitch / 4) + 1;
+        const unsigned* tr = t32 + __mul24(ys - tl.y0 + 4 + r0, kFPitch / 4) + gq - kUp;
         int code = __mul24(r0, kQCols) + 4 * gq;  // (row of the ring-grown tile, staged column)
         for (int rb = 0; rb < nrows; rb += kFPassRows, tr += kFPassRows * (kFPitch / 4), code += kFPassRows * kQCols) {
-            const bool valid = in_pass && rb + r0 < nrows;
-            // rows past the end read the last staged rows (still inside the buffer: kFPasses * kFPassRows + 3 + 4
-            // rows would be needed at most, so the row index is clamped instead)
-            const unsigned* trc = valid ? tr : t32 + 4 * (kFPitch / 4) + 1;
-            const unsigned C = trc[0], Lw = trc[-1], Rw = trc[1];
-            const unsigned P0 = trc[3 * (kFPitch / 4)], P8 = trc[-3 * (kFPitch / 4)];
+            // lanes without a row read the patch of equal pixels
+            const unsigned* trc = rb < rows_left ? tr : s_flat;
+            const unsigned C = trc[kUp], Lw = trc[kUp - 1], Rw = trc[kUp + 1];
+            const unsigned P0 = trc[kUp + 3 * (kFPitch / 4)], P8 = trc[kUp - 3 * (kFPitch / 4)];
             const unsigned P4 = __builtin_amdgcn_alignbyte(Rw, C, 3), P12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
             // any arc of nine covers two neighbouring compass points (ring positions 0, 4, 8, 12), one of {0, 8} and
             // one of {4, 12}: a corner needs min(max(p0, p8), max(p4, p12)) above the band or
             // max(min(p0, p8), min(p4, p12)) below it.  Both sides fold into ONE compare per pixel, so the scalar unit
             // (one per CU, shared by the four SIMDs) only counts bits.  Columns outside the scored range are dropped
             // when the queue is read (phase 2).
-            // Two pixels per instruction, without unpacking: one AND leaves the even bytes of a dword as two 16-bit
-            // values, another the odd bytes as two 16-bit values times 256.  Unsigned packed min / max order both forms
-            // alike, a saturating subtract keeps max(difference, 0) - all the compare against a threshold >= 0 needs -
-            // and the odd pixels are compared against the threshold times 256.
+            // Two pixels per instruction, without unpacking.  Even bytes: one AND leaves them as two 16-bit values;
+            // unsigned packed min / max and a saturating subtract (max(difference, 0) is all a compare against a
+            // threshold >= 0 needs) do the rest.  Odd bytes: the 16-bit halves are used AS THEY ARE.  The upper byte
+            // decides every unsigned 16-bit minimum and maximum, so the upper byte of each result is exact; the lower
+            // byte (the neighbouring pixel) only perturbs a difference by less than one unit of the upper byte.
+            // A pixel whose margin exceeds the threshold still exceeds threshold * 256 (margin >= t + 1 gives at least
+            // (t + 1) * 256 - 255); one whose margin equals the threshold may pass too, which only costs its score.
             unsigned long long pass[4];
             bool mine[4];
             int total = 0;
 #pragma unroll
             for (int hsel = 0; hsel < 2; hsel++) {
-                const unsigned keep = hsel ? 0xff00ff00u : 0x00ff00ffu;
+                const unsigned keep = hsel ? 0xffffffffu : 0x00ff00ffu;
                 const ushort2v v = as_ushort2v(C & keep);
                 const ushort2v p0 = as_ushort2v(P0 & keep), p4 = as_ushort2v(P4 & keep);
                 const ushort2v p8 = as_ushort2v(P8 & keep), p12 = as_ushort2v(P12 & keep);
@@ -509,8 +518,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
                 const ushort2v dn = __builtin_elementwise_sub_sat(
                     v, __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12)));
                 const ushort2v m = __builtin_elementwise_max(up, dn);
-                // lanes without a row carry a threshold nothing reaches
-                const unsigned thr16 = valid ? (unsigned)(hsel ? threshold << 8 : threshold) : 0xffffu;
+                const unsigned thr16 = (unsigned)(hsel ? threshold << 8 : threshold);
                 mine[hsel] = (unsigned)m.x > thr16;
                 mine[hsel + 2] = (unsigned)m.y > thr16;
                 pass[hsel] = __ballot(mine[hsel]);
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ at
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const unsigned ra = ctr[dy[k] * kFPitch + dx[k]], rb = ctr[dy[k + 8] * kFPitch + dx[k + 8]];
-            Q[k] = __builtin_bit_cast(half2v, ra | (rb << 16) | 0x64006400u);
+            Q[k] = __builtin_bit_cast(half2v, __builtin_amdgcn_perm(rb, ra, 0x0c040c00u) | 0x64006400u);
             Q[k + 8] = Q[k].yx;
         }
 #pragma unroll
