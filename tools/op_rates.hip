@@ -211,6 +211,17 @@ RATE_KERNEL3(k_bfi, "v_bfi_b32")
 RATE_KERNEL3(k_or3, "v_or3_b32")
 RATE_KERNEL3(k_xad, "v_xad_u32")
 RATE_KERNEL3(k_add3, "v_add3_u32")
+#define RATE_KERNEL_DPP(NAME, CTRL) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned c, int iters) { \
+    unsigned x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3; \
+    for (int i = 0; i < iters; i++) { R16(asm volatile("v_mov_b32_dpp %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(c) : "vcc");) } \
+    if ((x0 ^ x1 ^ x2 ^ x3) == 0x12345u) out[0] = x0; \
+}
+RATE_KERNEL_DPP(k_mov_dpp_row_shr, "row_shr:1")
+RATE_KERNEL_DPP(k_mov_dpp_wave_shr, "wave_shr:1")
+RATE_KERNEL_DPP(k_mov_dpp_wave_shl, "wave_shl:1")
+RATE_KERNEL_DPP(k_mov_dpp_quad, "quad_perm:[1,0,3,2]")
+RATE_KERNEL_DPP(k_mov_dpp_bcast15, "row_bcast:15")
 template <typename K> void run(const char* name, K kern, unsigned* d) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int blocks = 256 * 8, iters = 1024;
@@ -282,4 +293,9 @@ int main() { unsigned* d; (void)hipMalloc(&d, 64);
     run("or3", k_or3, d);
     run("xad", k_xad, d);
     run("add3", k_add3, d);
+    run("mov_dpp row_shr:1", k_mov_dpp_row_shr, d);
+    run("mov_dpp wave_shr:1", k_mov_dpp_wave_shr, d);
+    run("mov_dpp wave_shl:1", k_mov_dpp_wave_shl, d);
+    run("mov_dpp quad_perm", k_mov_dpp_quad, d);
+    run("mov_dpp row_bcast:15", k_mov_dpp_bcast15, d);
     return 0; }
