@@ -844,17 +844,25 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // K5/K6: Harris response (cv::ORB HarrisResponses, 7x7 block, k = 0.04) and intensity-centroid angle
 // (cv::ORB ICAngles, radius 15) of one candidate per wavefront.  Candidates whose FAST score is below the level's
 // retainBest(2*quota) value are skipped: cv::ORB has dropped them before it computes either quantity.
-// Harris: lane = one pixel of the block, three 4-byte row loads.  Angle: lane = half a patch row, four 4-byte loads,
-// byte sums and |u|-weighted byte sums by dot products (all integer, so the summation order does not matter).
+// Loads: lane = half a patch row, ONE 16-byte load per lane and candidate.  The kernel runs at the rate of the
+// texture addresser, which takes the lanes of a gather one by one, so nothing is loaded twice: the 9 x 9 pixels the
+// Harris block and its Sobel ring need are the middle of the patch rows -4 .. 4, and the lanes that hold them park
+// them in LDS.  Angle: byte sums and |u|-weighted byte sums by dot products (all integer, so the summation order does
+// not matter).  Harris: when kHarrisPark candidates are parked, eight of them are reduced at a time - a lane takes one
+// block row of one candidate, seven pixels in a row, from three parked patch rows.
 // cand_ro is the candidate array again, read-only: position, score and level of a record never change here (only its
 // response and angle are written), so the records can be fetched through the scalar path.
+constexpr int kHarrisPark = 16;
+
 __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
                                                       Cand* __restrict__ cand, const uint4* __restrict__ cand_ro,
                                                       int cap, const int* __restrict__ totals,
                                                       const int* __restrict__ thresholds, UMax umax,
                                                       float scale_sq_sq, int chunks, int frames) {
-    // per wavefront: the five sums and the index of up to 64 reduced candidates, finished 64 at a time (below)
-    __shared__ int s_res[4][64][6];
+    // per wavefront: the five sums and the index of the parked candidates, and their middle patch rows: row v + 4 of
+    // a block holds the pixels x - 7 .. x + 4 of patch row v (12 bytes of 16)
+    __shared__ int s_res[4][kHarrisPark][6];
+    __shared__ uint4 s_blk[4][kHarrisPark][9];
     const int lane = threadIdx.x & 63;
     int b, chunk;
     if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
@@ -882,81 +890,119 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
         }
         if (d < 0) msk[j] = 0u;
     }
-    const int hi = lane / 7 - 3, hj = lane - (lane / 7) * 7 - 3;
-    const int h_ofs = lane < 49 ? hi * aw + hj - 1 : -1;
     // The frame's candidates are dealt to chunks * 4 wavefronts.  A wavefront's work per candidate is a chain of
     // dependent loads (candidate -> pixels), so it runs as a software pipeline: the candidate record two steps
     // ahead and the pixels one step ahead are in flight while the current candidate is reduced.
     const int stride = chunks * 4;
-    const int idx0 = chunk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int idx0 = chunk * 4 + wv;
     const int thr_l = lane < kMaxLevels ? thresholds[b * kMaxLevels + lane] : 0;
     Cand* cbase = cand + (size_t)b * cap;
     const uint4* cro = cand_ro + (size_t)b * cap;
     const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
-    // per-lane offsets of the four loads from the candidate's centre pixel (an atlas is far smaller than 4 GB: the
-    // frame base stays a scalar pair and the lane offset a single 32-bit register)
-    const int hofs0 = h_ofs - aw, hofs2 = h_ofs + aw;
     // a candidate record is the same for all lanes: its index is wavefront-uniform, so it is read once per wavefront
     auto record = [&](int i) { return cro[min(i, max(total - 1, 0))]; };
-    struct Px { unsigned r0, r1, r2; uint4 q; bool live; };
+    struct Px { uint4 q; bool live; };
     auto fetch_px = [&](const uint4& rec, bool valid) {
         Px p;
-        p.r0 = p.r1 = p.r2 = 0u;
         p.q = make_uint4(0u, 0u, 0u, 0u);
         const unsigned xy = __builtin_amdgcn_readfirstlane(rec.x), sl = __builtin_amdgcn_readfirstlane(rec.y);
         const int lvl = (int)((sl >> 8) & (kMaxLevels - 1));
         p.live = valid && (int)(sl & 0xffu) >= __builtin_amdgcn_readlane(thr_l, lvl);
         if (p.live) {
             const LevelInfo L = g.L[lvl];
+            // per-lane offset from the candidate's centre pixel (an atlas is far smaller than 4 GB: the frame base
+            // stays a scalar pair and the lane offset a single 32-bit register)
             const int cofs = (L.y + (int)(xy >> 16)) * aw + L.x + (int)(xy & 0xffffu);
-            p.r0 = load_u32_any(fb + (unsigned)(cofs + hofs0));
-            p.r1 = load_u32_any(fb + (unsigned)(cofs + h_ofs));
-            p.r2 = load_u32_any(fb + (unsigned)(cofs + hofs2));
             p.q = load_u128_any(fb + (unsigned)(cofs + row_ofs));
         }
         return p;
     };
-    // The response and the angle of a candidate are scalar work (a division, a polynomial): done right after the
-    // reduction they would occupy the whole wavefront for one lane's result.  The sums are parked instead and every
-    // lane finishes one candidate when 64 have gathered (and once more at the end).
-    int (*res)[6] = s_res[threadIdx.x >> 6];
+    int (*res)[6] = s_res[wv];
+    uint4 (*blk)[9] = s_blk[wv];
     int n_res = 0;
-    // the sums of a candidate are ADDED into its parked record (see the reduction below): records start at zero
+    // the angle sums of a candidate are ADDED into its parked record (see the reduction below): they start at zero
+    if (lane < kHarrisPark) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) res[lane][k] = 0;
+        for (int k = 0; k < 6; k++) res[lane][k] = 0;
+    }
+    // parking place of this lane's part of a block (lanes 22 .. 39 hold patch rows -4 .. 4)
+    const bool parks = v >= -4 && v <= 4 && lane < 62;
+    const int park_row = min(max(v + 4, 0), 8);
     auto finish = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // Harris sums of the parked candidates, eight at a time: lane = (candidate, block row); byte 3 + k of a
+        // parked row is the pixel x - 4 + k
+        const int hc_ = lane >> 3, hr_ = lane & 7;
+        for (int p0 = 0; p0 < n_res; p0 += 8) {
+            const int c = p0 + hc_;
+            const int r = min(hr_, 6);
+            const uint4 A = blk[c][r], B = blk[c][r + 1], C = blk[c][r + 2];
+            int S[9], D[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int a_ = k == 0 ? (int)(A.x >> 24) : k < 5 ? (int)((A.y >> (8 * (k - 1))) & 255u) : (int)((A.z >> (8 * (k - 5))) & 255u);
+                const int b_ = k == 0 ? (int)(B.x >> 24) : k < 5 ? (int)((B.y >> (8 * (k - 1))) & 255u) : (int)((B.z >> (8 * (k - 5))) & 255u);
+                const int c_ = k == 0 ? (int)(C.x >> 24) : k < 5 ? (int)((C.y >> (8 * (k - 1))) & 255u) : (int)((C.z >> (8 * (k - 5))) & 255u);
+                S[k] = a_ + c_ + 2 * b_;   // the Sobel column sum: Ix = S[k + 1] - S[k - 1]
+                D[k] = c_ - a_;            // Iy = D[k - 1] + 2 D[k] + D[k + 1]
+            }
+            int ha = 0, hb = 0, hc = 0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) {
+                const int Ix = S[k + 1] - S[k - 1];
+                const int Iy = D[k - 1] + D[k + 1] + 2 * D[k];
+                ha += __mul24(Ix, Ix);
+                hb += __mul24(Iy, Iy);
+                hc += __mul24(Ix, Iy);
+            }
+            if (hr_ == 7) ha = hb = hc = 0;
+            // the seven block rows of a candidate sit in eight consecutive lanes: a running sum over 1, 2 and 4 lanes
+            // below leaves the candidate's totals in its last lane
+#define ORBX_ROW_SHR_ADD(ctrl)                                           \
+    ha += __builtin_amdgcn_update_dpp(0, ha, ctrl, 0xF, 0xF, true);      \
+    hb += __builtin_amdgcn_update_dpp(0, hb, ctrl, 0xF, 0xF, true);      \
+    hc += __builtin_amdgcn_update_dpp(0, hc, ctrl, 0xF, 0xF, true);
+            ORBX_ROW_SHR_ADD(0x111)  // row_shr:1 (zeros shifted in)
+            ORBX_ROW_SHR_ADD(0x112)  // row_shr:2
+            ORBX_ROW_SHR_ADD(0x114)  // row_shr:4
+#undef ORBX_ROW_SHR_ADD
+            if (hr_ == 7 && c < n_res) {
+                res[c][0] = ha;
+                res[c][1] = hb;
+                res[c][2] = hc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // The response and the angle of a candidate are scalar work (a division, a polynomial): every lane finishes
+        // one parked candidate
         if (lane < n_res) {
             const float fa = (float)res[lane][0], fb2 = (float)res[lane][1], fc = (float)res[lane][2];
             const float resp = (fa * fb2 - fc * fc - 0.04f * (fa + fb2) * (fa + fb2)) * scale_sq_sq;
             Cand* cp = cbase + res[lane][5];
             cp->harris = resp;
             cp->angle = fast_atan2_deg((float)res[lane][4], (float)res[lane][3]);
-#pragma unroll
-            for (int k = 0; k < 5; k++) res[lane][k] = 0;
+            res[lane][3] = 0;
+            res[lane][4] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         n_res = 0;
     };
-    const bool odd = lane & 1, upper = lane & 2;
+    const bool odd = lane & 1;
     auto process = [&](const Px& px, int idx) {
         if (!px.live) return;
-        const unsigned r0 = px.r0, r1 = px.r1, r2 = px.r2;
         const unsigned q[4] = {px.q.x, px.q.y, px.q.z, px.q.w};
-        int ha = 0, hb = 0, hc = 0;
-        if (lane < 49) {
-            const int a0 = r0 & 255, a1 = (r0 >> 8) & 255, a2 = (r0 >> 16) & 255;
-            const int b0 = r1 & 255, b2 = (r1 >> 16) & 255;
-            const int c0 = r2 & 255, c1 = (r2 >> 8) & 255, c2 = (r2 >> 16) & 255;
-            const int Ix = (b2 - b0) * 2 + (a2 - a0) + (c2 - c0);
-            const int Iy = (c1 - a1) * 2 + (c0 - a0) + (c2 - a2);
-            ha = Ix * Ix;
-            hb = Iy * Iy;
-            hc = Ix * Iy;
+        // the middle of patch rows -4 .. 4, for the Harris block: left halves bring x - 7 .. x, right halves x + 1 .. x + 4
+        if (parks) {
+            unsigned* row = (unsigned*)&blk[n_res][park_row];
+            if (right) row[2] = q[0];
+            else *(uint2*)row = make_uint2(q[2], q[3]);
         }
         unsigned ssum = 0, wsum = 0;
 #pragma unroll
@@ -965,26 +1011,18 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
             ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
             wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
         }
-        // Five sums over the wavefront at the price of about two.  Two exchanges inside each quad of lanes fold
-        // four of them into ONE register (lane & 3 = 0: sum Ix^2, 1: sum Iy^2, 2: sum IxIy, 3: m10 - each lane
-        // keeps the quantity of its class and hands the other one to its partner), two row shifts by 4 and 8 leave
-        // every row's class totals in its lanes 12..15, and those 16 lanes add them into the parked record in LDS.
-        // m01 takes the same steps in a register of its own.  All integer: the order of summation is free.
+        // Two sums over the wavefront at the price of one: the lanes of a pair exchange what the other one keeps
+        // (even lanes: m10, odd lanes: m01), the quad and two row shifts by 4 and 8 leave every row's totals in its
+        // lanes 12 (m10) and 13 (m01), which add them into the parked record in LDS.
         const int w10 = right ? (int)wsum : -(int)wsum, w01 = v * (int)ssum;
-        const int x1 = (odd ? hb : ha) + __builtin_amdgcn_update_dpp(0, odd ? ha : hb, 0xB1, 0xF, 0xF, false);
-        const int x2 = (odd ? w10 : hc) + __builtin_amdgcn_update_dpp(0, odd ? hc : w10, 0xB1, 0xF, 0xF, false);
-        int y = w01 + __builtin_amdgcn_update_dpp(0, w01, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-        int z = (upper ? x2 : x1) + __builtin_amdgcn_update_dpp(0, upper ? x1 : x2, 0x4E, 0xF, 0xF, false);
-        y += __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xF, 0xF, false);                  // quad_perm [2,3,0,1]
-        z += __builtin_amdgcn_update_dpp(0, z, 0x114, 0xF, 0xF, true);                  // row_shr:4, zeros shifted in
-        y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
-        z += __builtin_amdgcn_update_dpp(0, z, 0x118, 0xF, 0xF, true);                  // row_shr:8
-        y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
-        if ((lane & 12) == 12) atomicAdd(&res[n_res][lane & 3], z);
-        if ((lane & 15) == 15) atomicAdd(&res[n_res][4], y);
+        int z = (odd ? w01 : w10) + __builtin_amdgcn_update_dpp(0, odd ? w10 : w01, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        z += __builtin_amdgcn_update_dpp(0, z, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+        z += __builtin_amdgcn_update_dpp(0, z, 0x114, 0xF, 0xF, true);   // row_shr:4, zeros shifted in
+        z += __builtin_amdgcn_update_dpp(0, z, 0x118, 0xF, 0xF, true);   // row_shr:8
+        if ((lane & 14) == 12) atomicAdd(&res[n_res][3 + (lane & 1)], z);
         if (lane == 63) res[n_res][5] = idx;
         n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
-        if (n_res == 64) finish();
+        if (n_res == kHarrisPark) finish();
     };
     // two candidates per trip, in two sets of registers that take turns (no copies from "next" to "current")
     uint4 rec_a = record(idx0), rec_b = record(idx0 + stride);
