@@ -853,6 +853,9 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // cand_ro is the candidate array again, read-only: position, score and level of a record never change here (only its
 // response and angle are written), so the records can be fetched through the scalar path.
 constexpr int kHarrisPark = 16;
+// candidates of a wavefront whose pixels are in flight or being reduced (3, 4 and 6 measured the same as 2: the kernel
+// runs at the rate its gathers are addressed, not at their latency)
+constexpr int kHarrisAhead = 2;
 
 __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
                                                       Cand* __restrict__ cand, const uint4* __restrict__ cand_ro,
@@ -891,8 +894,8 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
         if (d < 0) msk[j] = 0u;
     }
     // The frame's candidates are dealt to chunks * 4 wavefronts.  A wavefront's work per candidate is a chain of
-    // dependent loads (candidate -> pixels), so it runs as a software pipeline: the candidate record two steps
-    // ahead and the pixels one step ahead are in flight while the current candidate is reduced.
+    // dependent loads (candidate -> pixels), so it runs as a software pipeline: the pixels of the next
+    // candidate and the record of the one after it are in flight while the current candidate is reduced.
     const int stride = chunks * 4;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idx0 = chunk * 4 + wv;
@@ -1024,16 +1027,27 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
         n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
         if (n_res == kHarrisPark) finish();
     };
-    // two candidates per trip, in two sets of registers that take turns (no copies from "next" to "current")
-    uint4 rec_a = record(idx0), rec_b = record(idx0 + stride);
-    Px px_a = fetch_px(rec_a, idx0 < total);
-    for (int idx = idx0; idx < total; idx += 2 * stride) {
-        rec_a = record(idx + 2 * stride);
-        const Px px_b = fetch_px(rec_b, idx + stride < total);
-        process(px_a, idx);
-        rec_b = record(idx + 3 * stride);
-        px_a = fetch_px(rec_a, idx + 2 * stride < total);
-        process(px_b, idx + stride);
+    // kHarrisAhead candidates per trip, in as many sets of registers that take turns (no copies from "next" to
+    // "current"): slot j holds the candidates j, j + kHarrisAhead, ... of this wavefront.  While a candidate is reduced
+    // the pixels of the next kHarrisAhead - 1 are in flight, and each slot already holds the record of its next one.
+    uint4 rec[kHarrisAhead];
+    Px px[kHarrisAhead];
+#pragma unroll
+    for (int k = 0; k < kHarrisAhead; k++) rec[k] = record(idx0 + k * stride);
+#pragma unroll
+    for (int k = 0; k < kHarrisAhead - 1; k++) {
+        px[k] = fetch_px(rec[k], idx0 + k * stride < total);
+        rec[k] = record(idx0 + (k + kHarrisAhead) * stride);
+    }
+    for (int idx = idx0; idx < total; idx += kHarrisAhead * stride) {
+#pragma unroll
+        for (int k = 0; k < kHarrisAhead; k++) {
+            constexpr int kLast = kHarrisAhead - 1;
+            const int j = (k + kLast) % kHarrisAhead;
+            px[j] = fetch_px(rec[j], idx + (k + kLast) * stride < total);
+            rec[j] = record(idx + (k + kLast + kHarrisAhead) * stride);
+            process(px[k], idx + k * stride);
+        }
     }
     if (n_res > 0) finish();
 }
