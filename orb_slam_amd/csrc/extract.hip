@@ -85,6 +85,8 @@ struct orbx_extractor {
     DevBuf<int32_t> d_cell_start, d_cell_items;
     PinBuf<int32_t> h_cell_start, h_cell_items;
     DevBuf<int> d_status;
+    DevBuf<int> d_kp_src;               // batch path: where each kept keypoint was detected (k_select_frame -> k_angle_kept)
+    bool harris_split = false;          // the last detect stage computed responses only (k_harris): no angles in d_cand
     DevBuf<unsigned char> d_select_ws;  // workspace of the selection kernel's global form
     FrameModel sel_fm;                  // what the last device selection ran with (more_global_passes repeats it)
     size_t sel_ws_stride = 0;
@@ -426,8 +428,27 @@ void launch_resize(orbx_extractor* h, int l, int frames, hipStream_t s) {
     }
 }
 
-// Ordered emission of the corners the FAST kernel marked, then Harris response and orientation of the candidates.
-void run_emit_and_harris(orbx_extractor* h, int frames) {
+// Harris response and orientation of every candidate above the retainBest(2 * quota) score, in one kernel.
+void launch_harris_angle(orbx_extractor* h, int frames) {
+    const int chunks = frames >= 64 ? 32 : 256;
+    hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, h->stream, h->d_atlas.p,
+                       h->atlas_bytes, h->geom, h->d_cand.p, (const uint4*)h->d_cand.p, h->cand_cap, h->d_totals.p,
+                       h->d_thresholds.p, h->umax, h->harris_scale_sq_sq, chunks, frames);
+    h->harris_split = false;
+}
+
+// Orientation of the keypoints the device selection kept (after k_harris and k_select_frame).
+void launch_angle_kept(orbx_extractor* h, int frames) {
+    // (8 to 64 chunks of four wavefronts per frame measured the same, for this kernel and for k_harris)
+    const int chunks = frames >= 64 ? 16 : 128;
+    hipLaunchKernelGGL(k_angle_kept, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, h->stream, h->d_atlas.p,
+                       h->atlas_bytes, h->geom, h->d_kp.p, h->d_kp_src.p, h->kp_cap, h->d_kp_counts.p, h->d_status.p,
+                       h->umax, chunks, frames);
+}
+
+// Ordered emission of the corners the FAST kernel marked, then Harris response and orientation of the candidates
+// (split: the response only - the caller runs the device selection and then launch_angle_kept).
+void run_emit_and_harris(orbx_extractor* h, int frames, bool split = false) {
     const Geom& g = h->geom;
     hipStream_t s = h->stream;
     size_t A = h->atlas_bytes;
@@ -442,12 +463,14 @@ void run_emit_and_harris(orbx_extractor* h, int frames) {
     }
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
-    {
-        const int chunks = frames >= 64 ? 32 : 256;
-        hipLaunchKernelGGL(k_harris_angle, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
-                           h->d_cand.p, (const uint4*)h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->umax,
-                           h->harris_scale_sq_sq,
-                           chunks, frames);
+    if (split) {
+        const int chunks = frames >= 64 ? 16 : 128;
+        hipLaunchKernelGGL(k_harris, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
+                           h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->harris_scale_sq_sq, chunks,
+                           frames);
+        h->harris_split = true;
+    } else {
+        launch_harris_angle(h, frames);
     }
     T.end(ST_HARRIS, s);
 }
@@ -470,7 +493,7 @@ orbx_status regrow_candidates(orbx_extractor* h, int frames, int needed) {
 
 // Pyramid + FAST + NMS + ordered emission + Harris/angle for `frames` device-resident images.
 orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int frames, size_t frame_stride, int w,
-                             int hgt, int stride, int ch, bool fork_blur = false) {
+                             int hgt, int stride, int ch, bool fork_blur = false, bool split_harris = false) {
     const Geom& g = h->geom;
     hipStream_t s = h->stream;
     size_t A = h->atlas_bytes;
@@ -507,7 +530,7 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
         ORBX_HIP(hipEventRecord(h->ev_blur, h->side_stream));
         h->blur_forked = true;
     }
-    run_emit_and_harris(h, frames);
+    run_emit_and_harris(h, frames, split_harris);
     ORBX_HIP(hipGetLastError());
     h->pyramid_valid = true;
     return ORBX_OK;
@@ -727,7 +750,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_mask.release(); h->d_steer.release(); h->d_cand.release(); h->d_packed.release();
     h->d_acc.release();
     h->d_thresholds.release(); h->d_totals.release(); h->d_offsets.release();
-    h->d_kp_counts.release(); h->d_kp.release();
+    h->d_kp_counts.release(); h->d_kp.release(); h->d_kp_src.release();
     h->h_packed.release(); h->h_ints.release(); h->h_kp.release(); h->h_desc.release();
     h->d_cell_start.release(); h->d_cell_items.release(); h->h_cell_start.release(); h->h_cell_items.release();
     h->d_status.release();
@@ -929,7 +952,7 @@ static orbx_status more_global_passes(orbx_extractor* h, int n_frames, int capac
         hipLaunchKernelGGL(k_select_frame<true>, dim3(n_frames), dim3(64 * h->geom.nlevels), 0, h->stream, h->d_cand.p,
                            h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, h->sel_fm, h->d_kp.p, capacity,
                            h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p, h->cand_cap, 2,
-                           h->d_select_ws.p, h->sel_ws_stride, h->sel_ws_slices, ws_counter);
+                           h->d_select_ws.p, h->sel_ws_stride, h->sel_ws_slices, ws_counter, h->d_kp_src.p);
         ORBX_HIP(hipMemcpyAsync(h_status, h->d_status.p, sizeof(int) * n_frames, hipMemcpyDeviceToHost, h->stream));
         ORBX_HIP(hipMemcpyAsync(h_cnt, h->d_kp_counts.p, sizeof(int) * n_frames, hipMemcpyDeviceToHost, h->stream));
         ORBX_HIP(hipStreamSynchronize(h->stream));
@@ -939,6 +962,7 @@ static orbx_status more_global_passes(orbx_extractor* h, int n_frames, int capac
     }
     *left = before;
     if (before == 0) {
+        launch_angle_kept(h, n_frames);   // every frame again: the same angles for those that had them
         ORBX_TRY(run_describe_stage(h, n_frames));
         ORBX_HIP(hipStreamSynchronize(h->stream));
     }
@@ -951,6 +975,9 @@ static orbx_status more_global_passes(orbx_extractor* h, int n_frames, int capac
 // candidates or keypoint slots.  The detect stage of the batch must be what the device buffers hold.
 static orbx_status batch_host_path(orbx_extractor* h, int n_frames, int width, int height, int capacity,
                                    orbx_keypoint* keypoints, int32_t* counts, uint8_t* descriptors) {
+    // the host selection reads the orientation from the candidates: a detect stage that left it to the device
+    // selection gets the combined kernel now (the same responses again, and the angles)
+    if (h->harris_split) launch_harris_angle(h, n_frames);
     std::vector<std::vector<orbx_keypoint>> sel;
     ORBX_TRY(select_keypoints(h, n_frames, sel));
     // MonoFrame::extractFeatures between detect and compute (mono_frame.cpp:85-100): undistort, bucket, filter
@@ -1048,7 +1075,6 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     ORBX_TRY(ensure_buffers(h, n_frames));
     h->last_frames = n_frames;
     BlurForkGuard fork_guard{h};  // whichever way this call ends, the side stream is joined
-    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, h->fork_blur));
 
     // Device-resident path: selection, undistortion, bucket grid and border filter run in one kernel per frame
     // (k_select_frame), so nothing crosses PCIe between detect and compute.  Its fast form keeps a frame's candidates
@@ -1063,8 +1089,13 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     // the grid (cell offsets + item lists) is built in the area of the selection elements, which are dead by then
     const size_t grid_ints = h->has_grid ? (size_t)ncell_dev + 1 + (size_t)capacity : 0;
     const bool lds_form = select_lds_full <= 160 * 1024 - 512 && grid_ints <= (size_t)kSelectMaxCands * 2;
-    if (h->device_select && h->geom.nlevels <= 16 && grid_ints <= (size_t)h->cand_cap * 2) {
+    const bool device_path = h->device_select && h->geom.nlevels <= 16 && grid_ints <= (size_t)h->cand_cap * 2;
+    // with the selection on the device the orientation is computed for the kept keypoints only, after it
+    ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, h->fork_blur,
+                              device_path));
+    if (device_path) {
         h->kp_cap = capacity;
+        ORBX_TRY(h->d_kp_src.ensure((size_t)capacity * n_frames));
         ORBX_TRY(h->d_kp.ensure((size_t)capacity * n_frames));
         ORBX_TRY(h->d_desc.ensure((size_t)capacity * n_frames * 32));
         ORBX_TRY(h->d_kp_counts.ensure(n_frames));
@@ -1109,7 +1140,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
             hipLaunchKernelGGL(k_select_frame<true>, dim3(n_frames), dim3(64 * h->geom.nlevels), 0, h->stream,
                                h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm, h->d_kp.p,
                                capacity, h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p,
-                               h->cand_cap, pass, h->d_select_ws.p, ws_stride, ws_slices, ws_counter);
+                               h->cand_cap, pass, h->d_select_ws.p, ws_stride, ws_slices, ws_counter, h->d_kp_src.p);
         };
         if (lds_form) {
             const size_t shmem = select_lds(kSelectMaxCands);
@@ -1128,7 +1159,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
                                    select_lds(max_cands), h->stream, h->d_cand.p, h->cand_cap, h->d_level_counts_p,
                                    h->d_totals.p, h->geom, fm, h->d_kp.p, capacity, h->d_kp_counts.p,
                                    h->d_cell_start.p, h->d_cell_items.p, h->d_status.p, max_cands, pass, nullptr, 0, 0,
-                                   nullptr);
+                                   nullptr, h->d_kp_src.p);
             };
             if (two_tier) {
                 launch_select(small_cands, 0);
@@ -1140,6 +1171,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         } else {
             launch_global(-1);
         }
+        launch_angle_kept(h, n_frames);
         h->timer.end(ST_SELECT, h->stream);
         ORBX_HIP(hipGetLastError());
         ORBX_TRY(run_describe_stage(h, n_frames));

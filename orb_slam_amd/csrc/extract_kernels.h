@@ -1052,6 +1052,228 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
     if (n_res > 0) finish();
 }
 
+// K5 by itself, for the batch path: the Harris response of the candidates above the retainBest(2 * quota) score and
+// nothing else - the orientation is only needed for the keypoints the selection keeps (k_angle_kept).  A response
+// needs nine rows of nine pixels, so ONE gather serves seven candidates: lane = (candidate, row), 16 bytes per lane
+// (the pixels x - 7 .. x + 8 of that row; bytes 3 .. 11 are used).  A wavefront takes 64 consecutive candidates,
+// lists the live ones (position in the atlas, index), and works the list off 28 at a time: four gathers in flight,
+// the rows parked in LDS, then lane = (candidate, block row) as in k_harris_angle, eight candidates per step.
+constexpr int kHarrisGroup = 7;                 // candidates per gather: 7 x 9 rows = 63 lanes
+constexpr int kHarrisRound = 4 * kHarrisGroup;  // candidates parked per round
+
+__global__ __launch_bounds__(256) void k_harris(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
+                                                Cand* __restrict__ cand, int cap, const int* __restrict__ totals,
+                                                const int* __restrict__ thresholds, float scale_sq_sq, int chunks,
+                                                int frames) {
+    __shared__ int2 s_list[4][64];
+    __shared__ uint4 s_blk[4][kHarrisRound + 4][9];   // the reduction reads whole steps of eight candidates
+    __shared__ int s_org[kMaxLevels];
+    const int lane = threadIdx.x & 63;
+    int b, chunk;
+    if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
+    const int total = min(totals[b], cap);
+    const int aw = g.atlas_w;
+    // atlas offset of every level's pixel (0, 0): the level differs from lane to lane here
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; l++)
+        if (threadIdx.x == l) s_org[l] = g.L[l].y * aw + g.L[l].x;
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Cand* cbase = cand + (size_t)b * cap;
+    const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
+    int2* list = s_list[wv];
+    uint4 (*blk)[9] = s_blk[wv];
+    const int c7 = div_small<9>(lane), row = lane - 9 * c7;   // lane 63: no candidate
+    const int row_ofs = (row - 4) * aw - 7;
+    const int hc_ = lane >> 3, hr_ = lane & 7;
+    auto fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int stride = chunks * 4 * 64;
+    for (int first = (chunk * 4 + wv) * 64; first < total; first += stride) {
+        const int i = first + lane;
+        bool live = false;
+        int cofs = 0;
+        if (i < total) {
+            const uint2 r = *(const uint2*)(cbase + i);   // x | y << 16, score | level << 8
+            const int lvl = (int)((r.y >> 8) & (kMaxLevels - 1));
+            live = (int)(r.y & 0xffu) >= thresholds[b * kMaxLevels + lvl];
+            cofs = s_org[lvl] + (int)(r.x >> 16) * aw + (int)(r.x & 0xffffu);
+        }
+        const unsigned long long m = __ballot(live);
+        const int nlive = __popcll(m);
+        if (live)
+            list[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+                make_int2(cofs, i);
+        fence();
+        for (int g0 = 0; g0 < nlive; g0 += kHarrisRound) {
+            const int n_round = min(kHarrisRound, nlive - g0);
+            uint4 q[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ci = kHarrisGroup * u + c7;
+                ok[u] = c7 < kHarrisGroup && ci < n_round;
+                q[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (ok[u]) q[u] = load_u128_any(fb + (unsigned)(list[g0 + ci].x + row_ofs));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (ok[u]) blk[kHarrisGroup * u + c7][row] = q[u];
+            fence();
+            // byte 3 + k of a parked row is the pixel x - 4 + k
+            for (int p0 = 0; p0 < n_round; p0 += 8) {
+                const int c = p0 + hc_;
+                const int r = min(hr_, 6);
+                const uint4 A = blk[c][r], B = blk[c][r + 1], C = blk[c][r + 2];
+                int S[9], D[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int a_ = k == 0 ? (int)(A.x >> 24) : k < 5 ? (int)((A.y >> (8 * (k - 1))) & 255u) : (int)((A.z >> (8 * (k - 5))) & 255u);
+                    const int b_ = k == 0 ? (int)(B.x >> 24) : k < 5 ? (int)((B.y >> (8 * (k - 1))) & 255u) : (int)((B.z >> (8 * (k - 5))) & 255u);
+                    const int c_ = k == 0 ? (int)(C.x >> 24) : k < 5 ? (int)((C.y >> (8 * (k - 1))) & 255u) : (int)((C.z >> (8 * (k - 5))) & 255u);
+                    S[k] = a_ + c_ + 2 * b_;   // the Sobel column sum: Ix = S[k + 1] - S[k - 1]
+                    D[k] = c_ - a_;            // Iy = D[k - 1] + 2 D[k] + D[k + 1]
+                }
+                int ha = 0, hb = 0, hc = 0;
+#pragma unroll
+                for (int k = 1; k < 8; k++) {
+                    const int Ix = S[k + 1] - S[k - 1];
+                    const int Iy = D[k - 1] + D[k + 1] + 2 * D[k];
+                    ha += __mul24(Ix, Ix);
+                    hb += __mul24(Iy, Iy);
+                    hc += __mul24(Ix, Iy);
+                }
+                if (hr_ == 7) ha = hb = hc = 0;
+                // a running sum over 1, 2 and 4 lanes leaves a candidate's totals in the last of its eight lanes
+#define ORBX_ROW_SHR_ADD(ctrl)                                           \
+    ha += __builtin_amdgcn_update_dpp(0, ha, ctrl, 0xF, 0xF, true);      \
+    hb += __builtin_amdgcn_update_dpp(0, hb, ctrl, 0xF, 0xF, true);      \
+    hc += __builtin_amdgcn_update_dpp(0, hc, ctrl, 0xF, 0xF, true);
+                ORBX_ROW_SHR_ADD(0x111)  // row_shr:1 (zeros shifted in)
+                ORBX_ROW_SHR_ADD(0x112)  // row_shr:2
+                ORBX_ROW_SHR_ADD(0x114)  // row_shr:4
+#undef ORBX_ROW_SHR_ADD
+                if (hr_ == 7 && c < n_round) {
+                    const float fa = (float)ha, fb2 = (float)hb, fc = (float)hc;
+                    cbase[list[g0 + c].y].harris = (fa * fb2 - fc * fc - 0.04f * (fa + fb2) * (fa + fb2)) * scale_sq_sq;
+                }
+            }
+            fence();   // the next round parks over these rows, the next block lists over these entries
+        }
+    }
+}
+
+// K6 for the keypoints the selection kept (batch path): the intensity-centroid angle of k_harris_angle, one keypoint
+// per wavefront and step.  src[frame][slot] holds where the keypoint was detected (x | y << 14 | level << 28, written
+// by k_select_frame: the keypoint's own coordinates may have been undistorted since); frames whose selection has not
+// finished (status != 0) have no keypoints yet.
+__global__ __launch_bounds__(256) void k_angle_kept(const uint8_t* __restrict__ atlas, size_t atlas_bytes, Geom g,
+                                                    orbx_keypoint* __restrict__ kps, const int* __restrict__ src,
+                                                    int kp_cap, const int* __restrict__ kp_counts,
+                                                    const int* __restrict__ status, UMax umax, int chunks,
+                                                    int frames) {
+    __shared__ int s_res[4][kHarrisPark][3];
+    const int lane = threadIdx.x & 63;
+    int b, chunk;
+    if (!frame_chunk_of_block(chunks, frames, b, chunk)) return;
+    const int total = status[b] == 0 ? min(kp_counts[b], kp_cap) : 0;
+    const int aw = g.atlas_w;
+    unsigned long long umax4 = 0ull;  // sixteen 4-bit row half-widths
+#pragma unroll
+    for (int k = 0; k < 16; k++) umax4 |= (unsigned long long)(umax.v[k] & 15) << (4 * k);
+    const int v = (lane >> 1) - 15;
+    const bool right = lane & 1;
+    const int d = lane < 62 ? (int)((umax4 >> (4 * (v < 0 ? -v : v))) & 15ull) : -1;
+    const int row_ofs = v * aw + (right ? 1 : -15);
+    unsigned msk[4], wgt[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (right) {  // byte i of the 16 holds u = i + 1; keep u <= d
+            const int keep = min(max(d - 4 * j, 0), 4);
+            msk[j] = keep == 0 ? 0u : 0xffffffffu >> (8 * (4 - keep));
+            wgt[j] = 0x04030201u + 0x04040404u * j;
+        } else {      // byte i holds u = i - 15; keep -u <= d
+            const int skip = min(max(15 - d - 4 * j, 0), 4);
+            msk[j] = skip == 4 ? 0u : 0xffffffffu << (8 * skip);
+            wgt[j] = 0x0c0d0e0fu - 0x04040404u * j;
+        }
+        if (d < 0) msk[j] = 0u;
+    }
+    const int stride = chunks * 4;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int idx0 = chunk * 4 + wv;
+    orbx_keypoint* kbase = kps + (size_t)b * kp_cap;
+    const int* sbase = src + (size_t)b * kp_cap;
+    const uint8_t* fb = atlas + (size_t)b * atlas_bytes;
+    // the slot is wavefront-uniform: its source word is read once per wavefront
+    auto source = [&](int i) { return sbase[min(i, max(total - 1, 0))]; };
+    auto fetch_px = [&](int word, bool valid) {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        const unsigned w = __builtin_amdgcn_readfirstlane((unsigned)word);
+        if (valid) {
+            const LevelInfo L = g.L[w >> 28];
+            const int cofs = (L.y + (int)((w >> 14) & 0x3fffu)) * aw + L.x + (int)(w & 0x3fffu);
+            q = load_u128_any(fb + (unsigned)(cofs + row_ofs));
+        }
+        return q;
+    };
+    int (*res)[3] = s_res[wv];
+    int n_res = 0;
+    if (lane < kHarrisPark) res[lane][0] = res[lane][1] = 0;   // the sums are ADDED into the parked record
+    auto fence = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto finish = [&]() {
+        fence();
+        if (lane < n_res) {   // the polynomial and the division are one lane's work per keypoint
+            kbase[res[lane][2]].angle = fast_atan2_deg((float)res[lane][1], (float)res[lane][0]);
+            res[lane][0] = 0;
+            res[lane][1] = 0;
+        }
+        fence();
+        n_res = 0;
+    };
+    const bool odd = lane & 1;
+    auto process = [&](const uint4& px, int idx) {
+        if (idx >= total) return;
+        const unsigned q[4] = {px.x, px.y, px.z, px.w};
+        unsigned ssum = 0, wsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned m = q[j] & msk[j];
+            ssum = __builtin_amdgcn_udot4(m, 0x01010101u, ssum, false);
+            wsum = __builtin_amdgcn_udot4(m, wgt[j], wsum, false);
+        }
+        // m10 and m01 in one reduction: the lanes of a pair exchange what the other one keeps (even: m10, odd: m01)
+        const int w10 = right ? (int)wsum : -(int)wsum, w01 = v * (int)ssum;
+        int z = (odd ? w01 : w10) + __builtin_amdgcn_update_dpp(0, odd ? w10 : w01, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        z += __builtin_amdgcn_update_dpp(0, z, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+        z += __builtin_amdgcn_update_dpp(0, z, 0x114, 0xF, 0xF, true);   // row_shr:4, zeros shifted in
+        z += __builtin_amdgcn_update_dpp(0, z, 0x118, 0xF, 0xF, true);   // row_shr:8
+        if ((lane & 14) == 12) atomicAdd(&res[n_res][lane & 1], z);
+        if (lane == 63) res[n_res][2] = idx;
+        n_res = __builtin_amdgcn_readfirstlane(n_res + 1);
+        if (n_res == kHarrisPark) finish();
+    };
+    // pixels of the next keypoint and the source word of the one after it in flight while this one is reduced
+    int src_a = source(idx0), src_b = source(idx0 + stride);
+    uint4 px_a = fetch_px(src_a, idx0 < total);
+    for (int idx = idx0; idx < total; idx += 2 * stride) {
+        src_a = source(idx + 2 * stride);
+        const uint4 px_b = fetch_px(src_b, idx + stride < total);
+        process(px_a, idx);
+        src_b = source(idx + 3 * stride);
+        px_a = fetch_px(src_a, idx + 2 * stride < total);
+        process(px_b, idx + stride);
+    }
+    if (n_res > 0) finish();
+}
+
 // Frame model of MonoFrame::extractFeatures for the device-resident batch path.
 struct FrameModel {
     int has_camera, has_grid;
@@ -1093,7 +1315,8 @@ __device__ __forceinline__ int compact_ordered(orbx_keypoint* s_kp, int n, int l
 // Device half of cv::ORB::detect after the kernels above, plus the host steps MonoFrame::extractFeatures performs
 // between detect and compute - one workgroup per frame, one wavefront per pyramid level:
 //   retainBest(2*quota) on the FAST score, retainBest(quota) on the Harris response (the level's wave replays
-//   libstdc++'s nth_element + partition, stdsel.h), keypoint assembly (size, angle, level-0 coordinates),
+//   libstdc++'s nth_element + partition, stdsel.h), keypoint assembly (size, angle, level-0 coordinates; with kp_src
+//   the angle is left to k_angle_kept and kp_src[frame][slot] receives the place of detection),
 //   Camera::undistortPoints, Frame::assignFeaturesToGrid (ordered filter + CSR cells), and the border filter of
 //   cv::ORB::compute.  status[frame]: 0 ok, 1 more keypoints than kp_cap, 2 more candidates than the LDS holds
 //   (3 between the two launches: left to the full-size one).
@@ -1110,7 +1333,7 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
                                                         int* __restrict__ cell_items, int* __restrict__ status,
                                                         int max_cands, int pass, unsigned char* __restrict__ ws,
                                                         size_t ws_stride, int ws_slices,
-                                                        int* __restrict__ ws_counter) {
+                                                        int* __restrict__ ws_counter, int* __restrict__ kp_src) {
     extern __shared__ __align__(16) unsigned char s_lds[];
     __shared__ int s_n[kMaxLevels], s_off[kMaxLevels], s_cnt, s_slice;
     typedef typename std::conditional<GLOBAL, uint32_t, uint16_t>::type St;
@@ -1209,7 +1432,9 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
             k.angle = c.angle;
             k.response = c.harris;
             k.octave = lvl;
-            k.class_id = -1;
+            // with kp_src the orientation is computed after this kernel, for the kept keypoints only: where the
+            // keypoint was detected travels in class_id until the final store
+            k.class_id = kp_src ? (int)((unsigned)c.x | (unsigned)c.y << 14 | (unsigned)lvl << 28) : -1;
             s_kp[oo + i] = k;
         }
     }
@@ -1323,7 +1548,14 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
         count = s_cnt;
     }
     orbx_keypoint* out = kps_out + (size_t)b * kp_cap;
-    for (int i = tid; i < count; i += blockDim.x) out[i] = s_kp[i];
+    for (int i = tid; i < count; i += blockDim.x) {
+        orbx_keypoint k = s_kp[i];
+        if (kp_src) {
+            kp_src[(size_t)b * kp_cap + i] = k.class_id;
+            k.class_id = -1;
+        }
+        out[i] = k;
+    }
     for (int i = count + tid; i < pre; i += blockDim.x) out[i] = orbx_keypoint{0.f, 0.f, 0.f, -1.f, 0.f, -128, -1};
     if (tid == 0) { kp_counts[b] = count; status[b] = 0; }
 }
