@@ -1776,6 +1776,8 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint8_t* sp8 = (const uint8_t*)s_patch[slot] + kBriefR * kBriefPitch + kBriefR;  // the centre pixel
+    constexpr float kMagic = 12582912.f;           // 1.5 * 2^23
+    constexpr unsigned kMagicBits = 0x4B400000u;   // its bit pattern
     int val = 0;
 #pragma unroll
     for (int bit = 0; bit < 8; bit++) {
@@ -1784,13 +1786,20 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ atlas
         const float px1 = (float)(int)(signed char)((pq >> 16) & 0xff), py1 = (float)(int)(signed char)(pq >> 24);
         const float x0 = px0 * a - py0 * bb, y0 = px0 * bb + py0 * a;
         const float x1 = px1 * a - py1 * bb, y1 = px1 * bb + py1 * a;
-        const int dx0 = __float2int_rn(x0), dy0 = __float2int_rn(y0);
-        const int dx1 = __float2int_rn(x1), dy1 = __float2int_rn(y1);
+        // cvRound without v_rndne + v_cvt (two half-rate instructions per coordinate): adding 1.5 * 2^23 rounds to
+        // the nearest even integer in the adder (|x| < 2^22), and the sum's bit pattern is kMagicBits + that integer
+        const unsigned bx0 = __float_as_uint(x0 + kMagic), by0 = __float_as_uint(y0 + kMagic);
+        const unsigned bx1 = __float_as_uint(x1 + kMagic), by1 = __float_as_uint(y1 + kMagic);
         int t0, t1;
         if (staged) {
-            t0 = sp8[__mul24(dy0, kBriefPitch) + dx0];
-            t1 = sp8[__mul24(dy1, kBriefPitch) + dx1];
+            // dy * pitch + dx straight from the bit patterns: the low 24 bits of by are 2^22 + dy, and the constants
+            // fold into the patch's base address
+            constexpr unsigned kFold = 0x400000u * (unsigned)kBriefPitch + kMagicBits;
+            t0 = sp8[(int)(__umul24(by0, (unsigned)kBriefPitch) + bx0 - kFold)];
+            t1 = sp8[(int)(__umul24(by1, (unsigned)kBriefPitch) + bx1 - kFold)];
         } else {
+            const int dx0 = (int)(bx0 - kMagicBits), dy0 = (int)(by0 - kMagicBits);
+            const int dx1 = (int)(bx1 - kMagicBits), dy1 = (int)(by1 - kMagicBits);
             const int sx0 = cx + dx0, sy0 = cy + dy0, sx1 = cx + dx1, sy1 = cy + dy1;
             const bool in0 = (unsigned)sx0 < (unsigned)lw && (unsigned)sy0 < (unsigned)lh;
             const bool in1 = (unsigned)sx1 < (unsigned)lw && (unsigned)sy1 < (unsigned)lh;

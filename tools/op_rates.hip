@@ -222,6 +222,17 @@ RATE_KERNEL_DPP(k_mov_dpp_wave_shr, "wave_shr:1")
 RATE_KERNEL_DPP(k_mov_dpp_wave_shl, "wave_shl:1")
 RATE_KERNEL_DPP(k_mov_dpp_quad, "quad_perm:[1,0,3,2]")
 RATE_KERNEL_DPP(k_mov_dpp_bcast15, "row_bcast:15")
+#define RATE_KERNEL_PK64(NAME, OP) \
+__global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned c, int iters) { \
+    unsigned long long x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3, cc = ((unsigned long long)c << 32) | c; \
+    for (int i = 0; i < iters; i++) { R16(asm volatile(OP " %0, %0, %4\n " OP " %1, %1, %4\n " OP " %2, %2, %4\n " OP " %3, %3, %4" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(cc) : "vcc");) } \
+    if ((x0 ^ x1 ^ x2 ^ x3) == 0x12345ull) out[0] = (unsigned)x0; \
+}
+RATE_KERNEL_PK64(k_pk_mul_f32, "v_pk_mul_f32")
+RATE_KERNEL_PK64(k_pk_add_f32, "v_pk_add_f32")
+RATE_KERNEL1(k_rndne_f32, "v_rndne_f32")
+RATE_KERNEL1(k_cvt_i32_f32, "v_cvt_i32_f32")
+RATE_KERNEL1(k_cvt_f32_i32, "v_cvt_f32_i32")
 template <typename K> void run(const char* name, K kern, unsigned* d) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int blocks = 256 * 8, iters = 1024;
@@ -298,4 +309,9 @@ int main() { unsigned* d; (void)hipMalloc(&d, 64);
     run("mov_dpp wave_shl:1", k_mov_dpp_wave_shl, d);
     run("mov_dpp quad_perm", k_mov_dpp_quad, d);
     run("mov_dpp row_bcast:15", k_mov_dpp_bcast15, d);
+    run("pk_mul_f32", k_pk_mul_f32, d);
+    run("pk_add_f32", k_pk_add_f32, d);
+    run("rndne_f32", k_rndne_f32, d);
+    run("cvt_i32_f32", k_cvt_i32_f32, d);
+    run("cvt_f32_i32", k_cvt_f32_i32, d);
     return 0; }
