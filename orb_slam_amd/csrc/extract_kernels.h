@@ -1708,14 +1708,16 @@ __global__ __launch_bounds__(256) void k_steer(Geom g, const orbx_keypoint* __re
     const int b = blockIdx.y;
     if (i >= counts[b] || i >= kp_cap) return;
     const orbx_keypoint kp = kps[(size_t)b * kp_cap + i];
-    const LevelInfo L = g.L[kp.octave];
+    // (the slots of a frame whose selection failed hold whatever was there: an octave or a centre out of range must
+    // not become an address - keypoints of a finished selection are never changed by the clamps)
+    const LevelInfo L = g.L[min((unsigned)kp.octave, (unsigned)(kMaxLevels - 1))];
     float angle = kp.angle;
     angle *= (float)(3.14159265358979323846 / 180.f);
     Steer s;
     s.a = (float)cos((double)angle);
     s.b = (float)sin((double)angle);
-    s.cx = __float2int_rn(kp.x * L.inv_scale);
-    s.cy = __float2int_rn(kp.y * L.inv_scale);
+    s.cx = min(max(__float2int_rn(kp.x * L.inv_scale), -13), L.w + 12);   // samples reach 18 further: inside the 32-pixel border
+    s.cy = min(max(__float2int_rn(kp.y * L.inv_scale), -13), L.h + 12);
     s.org = L.y * g.atlas_w + L.x;
     s.w = L.w;
     s.h = L.h;
