@@ -1362,8 +1362,18 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     const int total = totals[b];
     // pass 0: the launch with the small LDS leaves frames that do not fit it to pass 1 (status 3); pass 1 takes only
     // those; pass -1 is a single launch for every frame; pass 2 (global form) takes the frames an LDS launch left
+    // A frame this launch cannot finish leaves no keypoints and an EMPTY grid: whatever is queued behind the batch
+    // on the stream (a matcher walking the cells) then finds nothing instead of what an earlier batch left there.
+    auto leave_empty = [&](int st) {
+        if (fm.has_grid) {
+            const int ncell = fm.grid.grid_cols * fm.grid.grid_rows;
+            int* cs = cell_start + (size_t)b * (ncell + 1);
+            for (int i = tid; i <= ncell; i += blockDim.x) cs[i] = 0;
+        }
+        if (tid == 0) { status[b] = st; kp_counts[b] = 0; }
+    };
     if (total > max_cands || total > cand_cap) {
-        if (tid == 0) { status[b] = (pass == 0 && total <= cand_cap) ? 3 : 2; kp_counts[b] = 0; }
+        leave_empty((pass == 0 && total <= cand_cap) ? 3 : 2);
         return;
     }
     int n = 0, off = 0;
@@ -1417,7 +1427,7 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     __syncthreads();
     int count = s_cnt;
     if (count > kp_cap) {
-        if (tid == 0) { status[b] = 1; kp_counts[b] = count; }
+        leave_empty(1);
         return;
     }
     if (lvl < g.nlevels) {

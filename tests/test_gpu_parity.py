@@ -319,6 +319,47 @@ def test_compute_after_a_failed_batch(oracle, test_images):
     ex.close()
 
 
+def test_failed_frame_leaves_no_keypoints_and_an_empty_grid(oracle, test_images):
+    """A deferred batch returns before anybody has looked at the status words, and a matcher may already be queued
+    behind it on the stream.  A frame the device selection could not finish (here: more keypoints than the caller's
+    capacity) must therefore leave a count of zero and a grid without entries - never the grid an earlier batch left
+    in the buffer - and the neighbouring frame of the batch is unaffected."""
+    import torch
+    cam = orbx.make_camera(517.3, 516.5, 318.6, 255.3, TUM_DIST)
+    ocam = oracle.camera(517.3, 516.5, 318.6, 255.3, TUM_DIST, 640, 480)
+    grid = orbx.make_grid(oracle.image_bounds(ocam))
+    ncell = grid.grid_cols * grid.grid_rows
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=2)
+    ex.set_frame_model(cam, grid)
+    frames = [test_images[0], np.full_like(test_images[0], 90)]   # ~1000 keypoints, and none
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    cap = 1280
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), 2, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    assert counts[0] > 900 and counts[1] == 0
+    cs, _ = ex.device_grid()
+    full = torch.as_tensor(_DevView(cs, (2, ncell + 1), "<i4"), device="cuda").cpu().numpy().copy()
+    assert full[0, -1] > 900 and full[1, -1] == 0
+    # the same frames with room for 300 keypoints: frame 0 fails, frame 1 (no corners) is fine
+    small = 300
+    ex.extract_batch(dev.data_ptr(), 2, 640 * 480 * 3, 640, 480, 640 * 3, 3, small, to_host=False, deferred=True)
+    torch.cuda.synchronize()
+    cs, _ = ex.device_grid()
+    _, _, cnt_ptr, kcap = ex.device_results()
+    assert kcap == small
+    after = torch.as_tensor(_DevView(cs, (2, ncell + 1), "<i4"), device="cuda").cpu().numpy()
+    dcnt = torch.as_tensor(_DevView(cnt_ptr, (2,), "<i4"), device="cuda").cpu().numpy()
+    assert (after == 0).all() and (dcnt == 0).all()
+    with pytest.raises(orbx.OrbxError) as e:
+        ex.finish()
+    assert e.value.status == orbx.CAPACITY
+    # and the handle is as good as new
+    kps2, counts2, desc2 = ex.extract_batch(dev.data_ptr(), 2, 640 * 480 * 3, 640, 480, 640 * 3, 3, cap)
+    assert np.array_equal(counts2, counts) and np.array_equal(kps2[0, :counts[0]], kps[0, :counts[0]])
+    assert np.array_equal(desc2[0, :counts[0]], desc[0, :counts[0]])
+    ex.close()
+
+
 def test_selection_launch_tiers(oracle, test_images):
     """The selection kernel is launched with a small LDS footprint first and full-size for the frames left over; how
     many candidates the small launch holds depends on the keypoint capacity.  Capacities on both sides of every
