@@ -296,8 +296,9 @@ inline void set_grid(ProjArgs& A, const orbx_grid* g) {
 __device__ __forceinline__ void resolve_views(ProjArgs& A, int pair) {
     const int fi = A.frame_index ? A.frame_index[pair] : 0;
     const int ri = A.ref_index ? A.ref_index[pair] : 0;
-    A.n = A.counts ? A.counts[fi] : A.n;
-    A.n_ref = A.n_ref_pair ? A.n_ref_pair[pair] : (A.counts ? A.counts[ri] : A.n_ref);
+    // counts come from device memory another kernel wrote: whatever they hold, a frame has kp_stride slots
+    A.n = A.counts ? min(max(A.counts[fi], 0), (int)A.kp_stride) : A.n;
+    A.n_ref = A.n_ref_pair ? A.n_ref_pair[pair] : (A.counts ? min(max(A.counts[ri], 0), (int)A.kp_stride) : A.n_ref);
     A.kps += (size_t)fi * A.kp_stride;
     A.desc += (size_t)fi * A.kp_stride * 32;
     A.cell_start += (size_t)fi * A.cell_stride;
