@@ -77,7 +77,8 @@ def algorithmic_bytes(n_kp):
         "resize": sum(lv[l - 1][0] * lv[l - 1][1] + lv[l][0] * lv[l][1] for l in range(1, NLEVELS)),
         "fast": P + P // 8,                             # fused FAST + NMS: read pyramid, write 1 bit / pixel
         "emit": P // 8,                                 # read mask
-        "harris": 2 * n_kp * (81 + 709),                # 9x9 + radius-15 disc per surviving candidate (~2x quota)
+        "harris": 2 * n_kp * 81,                        # 9x9 per candidate above the retainBest(2 x quota) score
+        "angle": n_kp * 709,                            # radius-15 disc per kept keypoint
         "blur": 2 * P,                                  # read pyramid, write blurred pyramid
         "brief": n_kp * (512 + 32),                     # 512 samples + 32 descriptor bytes per keypoint
     }
@@ -324,7 +325,7 @@ def main():
     # HBM bytes per launch from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs of this command)
     traffic = None
     kernel_of = {"gray": "k_gray_level0", "resize": "k_resize_strip", "fast": "k_fast_nms", "emit": "k_emit",
-                 "harris": "k_harris_angle", "blur": "k_blur", "brief": "k_brief"}
+                 "harris": "k_harris", "angle": "k_angle_kept", "blur": "k_blur", "brief": "k_brief"}
     try:
         with open(os.path.join(ROOT, "profiles", args.profile_round + "_pmc_traffic.json")) as f:
             pmc = json.load(f).get(kernel_of[dom])

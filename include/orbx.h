@@ -160,7 +160,7 @@ orbx_status orbx_extractor_layout(const orbx_extractor* h, int width, int height
                                   int32_t* rects_xywh, float* layer_scales);
 orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, uint8_t* out, size_t out_bytes);
 /* Per-kernel launch durations (ms) of the last call, measured with HIP events on the handle's stream.
-   names: gray, resize, fast, nms, emit, harris, blur, brief, select.  Returns the number written (<= cap). */
+   names: gray, resize, fast, nms, emit, harris, blur, brief, select, angle.  Returns the number written (<= cap). */
 int orbx_extractor_last_timings(const orbx_extractor* h, float* ms, int cap);
 
 /* ------------------------------------------------------------------ matching -------------------------------- */

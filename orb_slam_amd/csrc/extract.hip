@@ -18,7 +18,7 @@ const int kBitPattern31[256 * 4] = {
 #include "bit_pattern_31.inc"
 };
 
-enum Stage { ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_NMS, ST_EMIT, ST_HARRIS, ST_BLUR, ST_BRIEF, ST_SELECT, ST_COUNT };
+enum Stage { ST_GRAY = 0, ST_RESIZE, ST_FAST, ST_NMS, ST_EMIT, ST_HARRIS, ST_BLUR, ST_BRIEF, ST_SELECT, ST_ANGLE, ST_COUNT };
 
 inline int cv_round(double v) { return (int)lrint(v); }
 inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
@@ -441,9 +441,11 @@ void launch_harris_angle(orbx_extractor* h, int frames) {
 void launch_angle_kept(orbx_extractor* h, int frames) {
     // (8 to 64 chunks of four wavefronts per frame measured the same, for this kernel and for k_harris)
     const int chunks = frames >= 64 ? 16 : 128;
+    h->timer.begin(ST_ANGLE, h->stream);
     hipLaunchKernelGGL(k_angle_kept, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, h->stream, h->d_atlas.p,
                        h->atlas_bytes, h->geom, h->d_kp.p, h->d_kp_src.p, h->kp_cap, h->d_kp_counts.p, h->d_status.p,
                        h->umax, chunks, frames);
+    h->timer.end(ST_ANGLE, h->stream);
 }
 
 // Ordered emission of the corners the FAST kernel marked, then Harris response and orientation of the candidates
@@ -1171,8 +1173,8 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         } else {
             launch_global(-1);
         }
-        launch_angle_kept(h, n_frames);
         h->timer.end(ST_SELECT, h->stream);
+        launch_angle_kept(h, n_frames);
         ORBX_HIP(hipGetLastError());
         ORBX_TRY(run_describe_stage(h, n_frames));
         ORBX_TRY(h->h_ints.ensure((size_t)n_frames * (2 * kMaxLevels + 2) + 1));

@@ -255,9 +255,9 @@ class Extractor:
         return kp.value, desc.value, cnt.value, cap.value
 
     def last_timings(self):
-        ms = np.zeros(9, np.float32)
-        n = lib().orbx_extractor_last_timings(self._h, _p(ms), 9)
-        names = ["gray", "resize", "fast", "nms", "emit", "harris", "blur", "brief", "select"]
+        ms = np.zeros(10, np.float32)
+        n = lib().orbx_extractor_last_timings(self._h, _p(ms), 10)
+        names = ["gray", "resize", "fast", "nms", "emit", "harris", "blur", "brief", "select", "angle"]
         return dict(zip(names[:n], ms[:n].tolist()))
 
 
