@@ -145,8 +145,8 @@ def cpu_baseline(frames_bgr, homs, grid_bounds, seconds=12.0, threads=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=792,
                     help="frames per GPU per step (792 = one TUM fr1/xyz-length sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
