@@ -907,12 +907,17 @@ __global__ __launch_bounds__(256) void k_gather_sorted(ProjArgs A, const ItemRec
     const int gl = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
     const int sub = (threadIdx.x >> 4) & 3;  // group inside the wavefront
-    // the per-level radius factors sit in LDS: one dependent memory round trip less per reference point
-    if ((int)threadIdx.x < min(A.n_levels, 64)) s_sf[threadIdx.x] = A.scale_factors[threadIdx.x];
-    __syncthreads();
-    A.scale_factors = s_sf;
+    // the per-level radius factors sit in LDS: one dependent memory round trip less per reference point.  Their load
+    // is in flight while the pair's views are resolved, and a block past the pair's last reference point (the grid is
+    // sized for the row capacity) leaves before the barrier
+    float sf = 0.f;
+    if ((int)threadIdx.x < min(A.n_levels, 64)) sf = A.scale_factors[threadIdx.x];
     const ItemRec* recs = recs_all + (size_t)blockIdx.y * A.kp_stride;
     resolve_views(A, blockIdx.y);
+    if ((int)blockIdx.x * 16 >= A.n_ref) return;
+    if (threadIdx.x < 64) s_sf[threadIdx.x] = sf;
+    __syncthreads();
+    A.scale_factors = s_sf;
     const int ref_idx = blockIdx.x * 16 + grp;
     if (ref_idx >= A.n_ref) return;
     const orbx_grid& g = A.g;
