@@ -424,6 +424,12 @@ orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int 
    v_add_f32 (the H scorer).  Multiply by 64 for lane-operations per second.  Runs on the NULL stream, about 1 ms. */
 orbx_status orbx_probe_issue_rate(int device, int kind, double* wave_instructions_per_second);
 
+/* Measurement hook (no counterpart in the reference): which kernel the brute-force Hamming entry points
+   (orbx_match_hamming, _batch, _cross) launch.  0 (default): the int8 matrix-core form, distance = |query| + the
+   dot product of the train bits as {0, 1} with the query bits as {+1, -1}; 1: the vector form (xor + popcount).
+   Same results bit for bit. */
+orbx_status orbx_matcher_set_hamming_kernel(orbx_matcher* h, int kind);
+
 /* Sets the HIP stream (hipStream_t as void*) a handle launches on; NULL restores the handle's own stream. */
 orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream);
 orbx_status orbx_matcher_set_stream(orbx_matcher* h, void* hip_stream);

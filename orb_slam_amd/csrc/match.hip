@@ -127,6 +127,135 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
     }
 }
 
+// K9 on the matrix cores.  The Hamming distance of two descriptors is a dot product: with the train bits a_k as
+// {0, 1} and the query bits b_k as b'_k = 1 - 2 b_k in {+1, -1},
+//     sum_k a_k b'_k = #(a=1, b=0) - #(a=1, b=1) = |a| - 2 #(a=1, b=1),   so   distance = |a| + |b| - 2 #(1, 1) = |b| + sum_k a_k b'_k:
+// the query's own popcount plus one exact int8 product per bit - 32 train rows x 32 queries x 32 bits per
+// v_mfma_i32_32x32x32_i8, eight of them per 32 x 32 tile of descriptor pairs.  A wavefront keeps the expanded fragments
+// of 64 queries (two tiles) in registers; a lane (r = lane & 31, h = lane >> 5) loads half h (128 bits) of train row r
+// of the current tile, expands 16 bits per step into 16 bytes (four bits per dword by one 24-bit multiply and a mask),
+// and the accumulator tile comes back with the lane's own query in all 16 registers (column = lane & 31, row =
+// (reg & 3) + 8 (reg >> 2) + 4 h), so the running minimum of key = distance << 16 | row is per lane and register: two
+// vector instructions per descriptor pair of a lane instead of seventeen.  Which bit sits in which slot of a fragment
+// does not matter as long as both operands use the same rule (they share spread16).  Same arguments, same packed-key
+// result and the same lowest-index-wins rule as k_bf_hamming.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ v4i_t spread16(unsigned hw) {   // 16 bits -> 16 bytes of 0 / 1
+    v4i_t r;
+    r.x = (int)(__umul24(hw & 0xfu, 0x204081u) & 0x01010101u);
+    r.y = (int)(__umul24((hw >> 4) & 0xfu, 0x204081u) & 0x01010101u);
+    r.z = (int)(__umul24((hw >> 8) & 0xfu, 0x204081u) & 0x01010101u);
+    r.w = (int)(__umul24((hw >> 12) & 0xfu, 0x204081u) & 0x01010101u);
+    return r;
+}
+
+constexpr int kMfmaQ = 2;                    // 32-query tiles per wavefront
+constexpr int kMfmaBlockQ = 4 * 32 * kMfmaQ;  // queries per workgroup
+
+__global__ __launch_bounds__(256) void k_bf_hamming_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr,
+                                                         int nq_const, size_t q_stride, const uint8_t* __restrict__ t,
+                                                         const int* __restrict__ nt_arr, int nt_const, size_t t_stride,
+                                                         int chunk, unsigned long long* __restrict__ best,
+                                                         size_t best_stride, int t_sets) {
+    const int p = blockIdx.z;
+    const int qs = t_sets > 0 ? p / t_sets : p, ts = t_sets > 0 ? p - qs * t_sets : p;
+    const int nq = nq_arr ? nq_arr[qs] : nq_const;
+    const int nt = nt_arr ? nt_arr[ts] : nt_const;
+    const int t0 = blockIdx.y * chunk;
+    const int t1 = min(nt, t0 + chunk);
+    if (blockIdx.x * kMfmaBlockQ >= nq || t0 >= t1) return;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * kMfmaBlockQ + (int)(threadIdx.x >> 6) * (32 * kMfmaQ);
+    if (q0 >= nq) return;
+    v4i_t bfrag[kMfmaQ][8];
+    unsigned base_q[kMfmaQ];
+#pragma unroll
+    for (int u = 0; u < kMfmaQ; u++) {
+        const int qi = q0 + 32 * u + r;
+        uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+        if (qi < nq) {
+            const uint4* qp = (const uint4*)(q + (size_t)qs * q_stride + (size_t)qi * 32);
+            qa = qp[0];
+            qb = qp[1];
+        }
+        base_q[u] = (unsigned)(__popc(qa.x) + __popc(qa.y) + __popc(qa.z) + __popc(qa.w) + __popc(qb.x) + __popc(qb.y) +
+                               __popc(qb.z) + __popc(qb.w)) << 16;
+        const uint4 half = h ? qb : qa;
+        const unsigned w[4] = {half.x, half.y, half.z, half.w};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const v4i_t sp = spread16((w[s >> 1] >> (16 * (s & 1))) & 0xffffu);
+            // 0 -> +1, 1 -> -1 in every byte (254 = 0xfe: no carry between bytes)
+            bfrag[u][s].x = (int)((unsigned)sp.x * 254u + 0x01010101u);
+            bfrag[u][s].y = (int)((unsigned)sp.y * 254u + 0x01010101u);
+            bfrag[u][s].z = (int)((unsigned)sp.z * 254u + 0x01010101u);
+            bfrag[u][s].w = (int)((unsigned)sp.w * 254u + 0x01010101u);
+        }
+    }
+    unsigned best_k[kMfmaQ][16];
+#pragma unroll
+    for (int u = 0; u < kMfmaQ; u++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) best_k[u][j] = 0xffffffffu;
+    const uint8_t* tp = t + (size_t)ts * t_stride + 16 * h;
+    auto load_half = [&](int row) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < t1) v = *(const uint4*)(tp + (size_t)row * 32);
+        return v;
+    };
+    uint4 cur = load_half(t0 + r);
+    for (int tb = t0; tb < t1; tb += 32) {
+        const uint4 nxt = load_half(tb + 32 + r);
+        const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
+        v16i_t acc[kMfmaQ];
+#pragma unroll
+        for (int u = 0; u < kMfmaQ; u++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[u][j] = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const v4i_t a = spread16((w[s >> 1] >> (16 * (s & 1))) & 0xffffu);
+#pragma unroll
+            for (int u = 0; u < kMfmaQ; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bfrag[u][s], acc[u], 0, 0, 0);
+        }
+        // row of register j within the tile: (j & 3) + 8 (j >> 2) + 4 h; the part that depends on j is added at the end
+        const unsigned rel = (unsigned)(tb - t0) + 4u * (unsigned)h;
+        if (tb + 32 <= t1) {   // wavefront-uniform: only the last tile of a chunk can have rows past the end
+#pragma unroll
+            for (int u = 0; u < kMfmaQ; u++) {
+                const unsigned base = base_q[u] + rel;
+#pragma unroll
+                for (int j = 0; j < 16; j++) best_k[u][j] = min(best_k[u][j], ((unsigned)acc[u][j] << 16) + base);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kMfmaQ; u++) {
+                const unsigned base = base_q[u] + rel;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    unsigned key = ((unsigned)acc[u][j] << 16) + base;
+                    if (tb + (j & 3) + 8 * (j >> 2) + 4 * h >= t1) key = 0xffffffffu;
+                    best_k[u][j] = min(best_k[u][j], key);
+                }
+            }
+        }
+        cur = nxt;
+    }
+#pragma unroll
+    for (int u = 0; u < kMfmaQ; u++) {
+        unsigned k = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (best_k[u][j] != 0xffffffffu) k = min(k, best_k[u][j] + (unsigned)((j & 3) + 8 * (j >> 2)));
+        const int qi = q0 + 32 * u + r;
+        if (qi < nq && k != 0xffffffffu)
+            atomicMin(&best[(size_t)p * best_stride + qi],
+                      ((unsigned long long)(k >> 16) << 32) | (unsigned)(t0 + (int)(k & 0xffffu)));
+    }
+}
+
 __global__ void k_unpack_best(const unsigned long long* __restrict__ best, size_t best_stride,
                               const int* __restrict__ nq_arr, int nq_const, int32_t* __restrict__ idx,
                               int32_t* __restrict__ dist, size_t out_stride, int t_sets) {
@@ -1606,6 +1735,7 @@ struct orbx_matcher {
     DevBuf<uint8_t> d_recs, d_args;
     size_t fast_lds_attr = 0, lists_lds_attr = 0, bow_lds_attr = 0, epi_lds_attr = 0;
     std::vector<unsigned long long> h_best;
+    int hamming_kernel = 0;   // 0: matrix cores (k_bf_hamming_mfma), 1: vector pipes (k_bf_hamming)
 };
 
 namespace {
@@ -1638,11 +1768,13 @@ orbx_status hamming_sets(orbx_matcher* h, const uint8_t* d_query, const int32_t*
     ORBX_HIP(hipMemsetAsync(h->d_best.p, 0xff, nb * sizeof(unsigned long long), s));
     const int qb = div_up(max_query, 256);
     if (max_train > 0) {
-        const int hb = div_up(max_query, kHamBlockQ);
+        const bool mfma = h->hamming_kernel == 0;
+        const int hb = div_up(max_query, mfma ? kMfmaBlockQ : kHamBlockQ);
         const int chunk = pick_chunk(max_train, hb, n_pairs);
         dim3 grid(hb, div_up(max_train, chunk), n_pairs);
-        hipLaunchKernelGGL(k_bf_hamming, grid, dim3(256), 0, s, d_query, d_n_query, max_query, query_stride, d_train,
-                           d_n_train, max_train, train_stride, chunk, h->d_best.p, (size_t)max_query, t_sets);
+        hipLaunchKernelGGL(mfma ? k_bf_hamming_mfma : k_bf_hamming, grid, dim3(256), 0, s, d_query, d_n_query, max_query,
+                           query_stride, d_train, d_n_train, max_train, train_stride, chunk, h->d_best.p,
+                           (size_t)max_query, t_sets);
     }
     hipLaunchKernelGGL(k_unpack_best, dim3(qb, n_pairs), dim3(256), 0, s, h->d_best.p, (size_t)max_query, d_n_query,
                        max_query, d_train_idx, d_distance, out_stride, t_sets);
@@ -1683,6 +1815,12 @@ void orbx_matcher_destroy(orbx_matcher* h) {
 orbx_status orbx_matcher_set_stream(orbx_matcher* h, void* hip_stream) {
     if (!h) return ORBX_BAD_ARG;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return ORBX_OK;
+}
+
+orbx_status orbx_matcher_set_hamming_kernel(orbx_matcher* h, int kind) {
+    if (!h || (kind != 0 && kind != 1)) return ORBX_BAD_ARG;
+    h->hamming_kernel = kind;
     return ORBX_OK;
 }
 

@@ -32,7 +32,7 @@ SYMBOLS = [
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
-    "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream",
+    "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream", "orbx_matcher_set_hamming_kernel",
 ]
 
 
@@ -299,6 +299,9 @@ class Matcher:
 
     def set_stream(self, stream_ptr):
         _check(lib().orbx_matcher_set_stream(self._h, C.c_void_p(stream_ptr)), "orbx_matcher_set_stream")
+
+    def set_hamming_kernel(self, kind):
+        _check(lib().orbx_matcher_set_hamming_kernel(self._h, int(kind)), "orbx_matcher_set_hamming_kernel")
 
     def match_hamming(self, query, train):
         q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)

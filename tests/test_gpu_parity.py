@@ -467,10 +467,20 @@ def test_match_hamming_bit_exact(oracle, matcher, ex1000, test_images):
     cases.append((t[rng.integers(0, 600, 900)].copy(), np.concatenate([t, t])))
     r = [ex1000.compute(img, ex1000.detect(img)) for img in test_images]
     cases.append((r[0][1], r[1][1]))
-    for q, tr in cases:
-        idx, dist = matcher.match_hamming(q, tr)
-        oidx, odist = oracle.match_hamming(q, tr)
-        assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    # sizes around the 32-row tiles and the 64- / 256-query blocks of the matrix-core kernel; all-zero and all-one rows
+    # (distances 0 and 256, the ends of the dot product's range)
+    for nq, nt in ((31, 33), (32, 32), (33, 31), (63, 65), (64, 64), (65, 63), (255, 1), (256, 2), (300, 97)):
+        cases.append((rng.integers(0, 256, (nq, 32), dtype=np.uint8), rng.integers(0, 256, (nt, 32), dtype=np.uint8)))
+    ends = np.concatenate([np.zeros((3, 32), np.uint8), np.full((3, 32), 255, np.uint8),
+                           rng.integers(0, 256, (70, 32), dtype=np.uint8)])
+    cases.append((ends, ends[::-1].copy()))
+    for kind in (0, 1):   # matrix cores, vector pipes
+        matcher.set_hamming_kernel(kind)
+        for q, tr in cases:
+            idx, dist = matcher.match_hamming(q, tr)
+            oidx, odist = oracle.match_hamming(q, tr)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (kind, q.shape, tr.shape)
+    matcher.set_hamming_kernel(0)
     idx, dist = matcher.match_hamming(cases[2][0], np.zeros((0, 32), np.uint8))
     assert np.all(idx == -1) and np.all(dist == -1)
     # ORBMatcher::match(..., filter=true) end to end
