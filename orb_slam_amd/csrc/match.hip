@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
 // of the current tile, expands 16 bits per step into 16 bytes (four bits per dword by one 24-bit multiply and a mask),
 // and the accumulator tile comes back with the lane's own query in all 16 registers (column = lane & 31, row =
 // (reg & 3) + 8 (reg >> 2) + 4 h), so the running minimum of key = distance << 16 | row is per lane and register: two
-// vector instructions per descriptor pair of a lane instead of seventeen.  Which bit sits in which slot of a fragment
+// vector instructions per descriptor pair of a lane instead of seventeen (they share the SIMD's issue with the
+// products and set the pace: the matrix pipe is busy 40-45 % of the time).  Which bit sits in which slot of a fragment
 // does not matter as long as both operands use the same rule (they share spread16).  Same arguments, same packed-key
 // result and the same lowest-index-wins rule as k_bf_hamming.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -152,9 +153,10 @@ __device__ __forceinline__ v4i_t spread16(unsigned hw) {   // 16 bits -> 16 byte
 }
 
 constexpr int kMfmaQ = 2;                    // 32-query tiles per wavefront
+constexpr int kMfmaSub = 1;                  // 32-row train tiles per barrier (2 and 4 measured the same)
 constexpr int kMfmaBlockQ = 4 * 32 * kMfmaQ;  // queries per workgroup
 
-__global__ __launch_bounds__(256) void k_bf_hamming_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr,
+__global__ __launch_bounds__(256, 2) void k_bf_hamming_mfma(const uint8_t* __restrict__ q, const int* __restrict__ nq_arr,
                                                          int nq_const, size_t q_stride, const uint8_t* __restrict__ t,
                                                          const int* __restrict__ nt_arr, int nt_const, size_t t_stride,
                                                          int chunk, unsigned long long* __restrict__ best,
@@ -167,8 +169,14 @@ __global__ __launch_bounds__(256) void k_bf_hamming_mfma(const uint8_t* __restri
     const int t1 = min(nt, t0 + chunk);
     if (blockIdx.x * kMfmaBlockQ >= nq || t0 >= t1) return;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * kMfmaBlockQ + (int)(threadIdx.x >> 6) * (32 * kMfmaQ);
-    if (q0 >= nq) return;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q0 = blockIdx.x * kMfmaBlockQ + wv * (32 * kMfmaQ);
+    const bool has_queries = q0 < nq;   // a wavefront without queries still expands its share of every train tile
+    // The expanded train tiles are the same for the four wavefronts of the workgroup: each expands two of the eight
+    // steps (one dword of its lanes' row halves) into LDS, fragment-major, so that writes and reads are whole
+    // 16-byte words of consecutive lanes.  A stage is kMfmaSub tiles of 32 rows; two stage buffers, one barrier per
+    // stage.
+    __shared__ uint4 s_frag[2][kMfmaSub][8][64];
     v4i_t bfrag[kMfmaQ][8];
     unsigned base_q[kMfmaQ];
 #pragma unroll
@@ -199,50 +207,90 @@ __global__ __launch_bounds__(256) void k_bf_hamming_mfma(const uint8_t* __restri
     for (int u = 0; u < kMfmaQ; u++)
 #pragma unroll
         for (int j = 0; j < 16; j++) best_k[u][j] = 0xffffffffu;
-    const uint8_t* tp = t + (size_t)ts * t_stride + 16 * h;
-    auto load_half = [&](int row) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < t1) v = *(const uint4*)(tp + (size_t)row * 32);
+    // dword wv of half h of train row (tile + r): steps 2 wv and 2 wv + 1 of this lane's fragments
+    const uint8_t* tp = t + (size_t)ts * t_stride + 16 * h + 4 * wv;
+    auto load_word = [&](int row) {
+        unsigned v = 0u;
+        if (row < t1) v = *(const unsigned*)(tp + (size_t)row * 32);
         return v;
     };
-    uint4 cur = load_half(t0 + r);
-    for (int tb = t0; tb < t1; tb += 32) {
-        const uint4 nxt = load_half(tb + 32 + r);
-        const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
-        v16i_t acc[kMfmaQ];
+    auto expand_into = [&](int buf, int sub, unsigned word) {
+        const v4i_t lo = spread16(word & 0xffffu), hi = spread16(word >> 16);
+        s_frag[buf][sub][2 * wv][lane] = make_uint4((unsigned)lo.x, (unsigned)lo.y, (unsigned)lo.z, (unsigned)lo.w);
+        s_frag[buf][sub][2 * wv + 1][lane] = make_uint4((unsigned)hi.x, (unsigned)hi.y, (unsigned)hi.z, (unsigned)hi.w);
+    };
+    constexpr int kStageRows = 32 * kMfmaSub;
+    unsigned nxt[kMfmaSub];
 #pragma unroll
-        for (int u = 0; u < kMfmaQ; u++)
+    for (int sub = 0; sub < kMfmaSub; sub++) expand_into(0, sub, load_word(t0 + 32 * sub + r));
 #pragma unroll
-            for (int j = 0; j < 16; j++) acc[u][j] = 0;
+    for (int sub = 0; sub < kMfmaSub; sub++) nxt[sub] = load_word(t0 + kStageRows + 32 * sub + r);
+    __syncthreads();
+    int buf = 0;
+    for (int sb = t0; sb < t1; sb += kStageRows, buf ^= 1) {
+        unsigned word[kMfmaSub];
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const v4i_t a = spread16((w[s >> 1] >> (16 * (s & 1))) & 0xffffu);
-#pragma unroll
-            for (int u = 0; u < kMfmaQ; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bfrag[u][s], acc[u], 0, 0, 0);
+        for (int sub = 0; sub < kMfmaSub; sub++) {
+            word[sub] = nxt[sub];
+            nxt[sub] = load_word(sb + 2 * kStageRows + 32 * sub + r);
         }
-        // row of register j within the tile: (j & 3) + 8 (j >> 2) + 4 h; the part that depends on j is added at the end
-        const unsigned rel = (unsigned)(tb - t0) + 4u * (unsigned)h;
-        if (tb + 32 <= t1) {   // wavefront-uniform: only the last tile of a chunk can have rows past the end
+        if (has_queries) {
 #pragma unroll
-            for (int u = 0; u < kMfmaQ; u++) {
-                const unsigned base = base_q[u] + rel;
+            for (int sub = 0; sub < kMfmaSub; sub++) {
+                const int tb = sb + 32 * sub;
+                if (tb >= t1) break;   // workgroup-uniform
+                v16i_t acc[kMfmaQ];
 #pragma unroll
-                for (int j = 0; j < 16; j++) best_k[u][j] = min(best_k[u][j], ((unsigned)acc[u][j] << 16) + base);
-            }
-        } else {
+                for (int u = 0; u < kMfmaQ; u++)
 #pragma unroll
-            for (int u = 0; u < kMfmaQ; u++) {
-                const unsigned base = base_q[u] + rel;
+                    for (int j = 0; j < 16; j++) acc[u][j] = 0;
+                // all eight fragment reads of the tile are issued before the first product needs one
+                v4i_t a[8];
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    unsigned key = ((unsigned)acc[u][j] << 16) + base;
-                    if (tb + (j & 3) + 8 * (j >> 2) + 4 * h >= t1) key = 0xffffffffu;
-                    best_k[u][j] = min(best_k[u][j], key);
+                for (int s = 0; s < 8; s++) {
+                    const uint4 f = s_frag[buf][sub][s][lane];
+                    a[s].x = (int)f.x;
+                    a[s].y = (int)f.y;
+                    a[s].z = (int)f.z;
+                    a[s].w = (int)f.w;
                 }
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+#pragma unroll
+                    for (int u = 0; u < kMfmaQ; u++)
+                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bfrag[u][s], acc[u], 0, 0, 0);
+                // row of register j within the tile: (j & 3) + 8 (j >> 2) + 4 h; the part that depends on j is added
+                // at the end
+                const unsigned rel = (unsigned)(tb - t0) + 4u * (unsigned)h;
+                unsigned key[kMfmaQ][16];
+#pragma unroll
+                for (int u = 0; u < kMfmaQ; u++) {
+                    const unsigned base = base_q[u] + rel;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) key[u][j] = ((unsigned)acc[u][j] << 16) + base;
+                }
+                if (tb + 32 > t1) {   // workgroup-uniform: only the last tile of a chunk can have rows past the end
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        if (tb + (j & 3) + 8 * (j >> 2) + 4 * h >= t1) {
+#pragma unroll
+                            for (int u = 0; u < kMfmaQ; u++) key[u][j] = 0xffffffffu;
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < kMfmaQ; u++)
+#pragma unroll
+                    for (int j = 0; j < 16; j++) best_k[u][j] = min(best_k[u][j], key[u][j]);
             }
         }
-        cur = nxt;
+        // the next stage goes into the other buffer, which every wavefront finished reading before the last barrier
+        if (sb + kStageRows < t1) {
+#pragma unroll
+            for (int sub = 0; sub < kMfmaSub; sub++) expand_into(buf ^ 1, sub, word[sub]);
+        }
+        __syncthreads();
     }
+    if (!has_queries) return;
 #pragma unroll
     for (int u = 0; u < kMfmaQ; u++) {
         unsigned k = 0xffffffffu;
