@@ -474,6 +474,9 @@ def test_match_hamming_bit_exact(oracle, matcher, ex1000, test_images):
     ends = np.concatenate([np.zeros((3, 32), np.uint8), np.full((3, 32), 255, np.uint8),
                            rng.integers(0, 256, (70, 32), dtype=np.uint8)])
     cases.append((ends, ends[::-1].copy()))
+    # more train rows than one chunk's 16-bit row index covers; the best row of some queries sits in the second chunk
+    big = rng.integers(0, 256, (70000, 32), dtype=np.uint8)
+    cases.append((np.concatenate([big[[69999, 65536, 65535, 12]], rng.integers(0, 256, (36, 32), dtype=np.uint8)]), big))
     for kind in (0, 1):   # matrix cores, vector pipes
         matcher.set_hamming_kernel(kind)
         for q, tr in cases:
