@@ -44,6 +44,13 @@ template <typename T> struct Point3_ {
     Point3_(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
 };
 typedef Point3_<double> Point3d;
+struct Vec3f {
+    float val[3];
+    Vec3f() : val{0.f, 0.f, 0.f} {}
+    Vec3f(float a, float b, float c) : val{a, b, c} {}
+    float& operator[](int i) { return val[i]; }
+    const float& operator[](int i) const { return val[i]; }
+};
 struct KeyPoint {
     Point2f pt;
     float size, angle, response;
@@ -76,7 +83,18 @@ public:
     template <typename T> const T* ptr(int r = 0) const { return (const T*)(data + step * r); }
     template <typename T> T& at(int r, int c) { return ptr<T>(r)[c]; }
     template <typename T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
-    Mat clone() const { Mat m(rows, cols, type()); if (!empty()) std::memcpy(m.data, data, (size_t)rows * step); return m; }
+    Mat clone() const {
+        Mat m(rows, cols, type());
+        for (int r = 0; r < rows && cols > 0; r++) std::memcpy(m.data + m.step * r, data + step * r, (size_t)cols * esz_);
+        return m;
+    }
+    /* header over row r, sharing this matrix' storage (cv::Mat::row) */
+    Mat row(int r) const {
+        Mat m;
+        m.rows = 1; m.cols = cols; m.type_ = type_; m.ch_ = ch_; m.esz_ = esz_;
+        m.buf_ = buf_; m.data = data + step * r; m.step = step;
+        return m;
+    }
     void release() { rows = cols = 0; buf_.reset(); data = nullptr; }
     unsigned char* data = nullptr;
     size_t step = 0;

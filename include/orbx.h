@@ -384,6 +384,23 @@ orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float*
                                const uint32_t* sets8, int iterations, double sigma,
                                float* F_all, float* H_all, float* Hinv_all, float* score_f, float* score_h);
 
+/* The three public solvers of the reference's geometry/utils.h, for ANY number of correspondences (the RANSAC entry
+   points above run them on the 8-point sets of their hypotheses).  Host pointers in and out.
+
+   orbx_normalize_points replaces geometry::normalizePoints (include/orb_slam/geometry/utils.h:24-27,
+   src/geometry/utils.cpp:18-52): normalized receives n (x, y) pairs, T9 the row-major 3x3 transform.
+   orbx_fundamental_npt replaces geometry::computeFundamentalMat (utils.h:36-39, utils.cpp:61-103): the n x 9
+   system, cv::SVDecomp, vt.row(8), rank-2 enforcement by a second SVD.
+   orbx_homography_dlt replaces geometry::computeHomographyMat (utils.h:48-51, utils.cpp:112-154): the 2n x 9 system,
+   vt.row(8).
+   Both solvers take n_systems independent systems of n correspondences each, back to back (system q owns points
+   q*n .. q*n + n - 1 and row q of the 9-float output); the reference's functions are the n_systems = 1 case. */
+orbx_status orbx_normalize_points(orbx_ransac* h, const float* points, int n, float* normalized, float* T9);
+orbx_status orbx_fundamental_npt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems,
+                                 float* F9);
+orbx_status orbx_homography_dlt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems,
+                                float* H9);
+
 /* Replaces Initializer::findRtWithFundamental (src/Initializer.cpp:165-199) for a batch of frame pairs: E = K^T F K
    as the reference forms it (CV_32F), then cv::recoverPose(E, inlier_ref_points, inlier_points, R, t, focal, pp) of
    OpenCV 3.4 in double (decomposeEssentialMat, triangulation of every correspondence against the four candidate

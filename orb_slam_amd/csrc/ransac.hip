@@ -351,6 +351,64 @@ orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float*
     return ORBX_OK;
 }
 
+// ---- the public solvers of geometry/utils.h for any number of correspondences ---------------------------------
+
+orbx_status orbx_normalize_points(orbx_ransac* h, const float* points, int n, float* normalized, float* T9) {
+    if (!h || !points || !normalized || !T9 || n <= 0) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    ORBX_TRY(h->d_pts.ensure((size_t)n * 2));
+    ORBX_TRY(h->d_pn.ensure((size_t)n * 2));
+    ORBX_TRY(h->d_T.ensure(18));
+    ORBX_HIP(hipMemcpyAsync(h->d_pts.p, points, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    // one point set: side 0 of a single pair (the reference-side arguments are never touched)
+    hipLaunchKernelGGL(k_normalize, dim3(1, 1), dim3(64), 0, s, h->d_pts.p, h->d_pts.p, n, h->d_pn.p, h->d_pn.p,
+                       h->d_T.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(normalized, h->d_pn.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(T9, h->d_T.p, sizeof(float) * 9, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+
+}  // extern "C"
+
+namespace {
+orbx_status solve_npt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems, int model,
+                      float* out9) {
+    if (!h || !points || !ref_points || !out9 || n <= 0 || n_systems <= 0) return ORBX_BAD_ARG;
+    if ((long long)n * n_systems > (1ll << 28)) return ORBX_CAPACITY;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t total = (size_t)n * n_systems;
+    const int rows = model == 0 ? n : 2 * n;
+    ORBX_TRY(h->d_pts.ensure(total * 2));
+    ORBX_TRY(h->d_ref.ensure(total * 2));
+    ORBX_TRY(h->d_Fall.ensure((size_t)9 * std::max(rows, 9) * n_systems));  // the systems' rows, worked on in place
+    ORBX_TRY(h->d_F.ensure((size_t)9 * n_systems));
+    ORBX_HIP(hipMemcpyAsync(h->d_pts.p, points, sizeof(float) * 2 * total, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_ref.p, ref_points, sizeof(float) * 2 * total, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_solve_npt, dim3(n_systems), dim3(64), 0, s, h->d_pts.p, h->d_ref.p, n, model, h->d_Fall.p,
+                       h->d_F.p);
+    ORBX_HIP(hipGetLastError());
+    ORBX_HIP(hipMemcpyAsync(out9, h->d_F.p, sizeof(float) * 9 * n_systems, hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    return ORBX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+orbx_status orbx_fundamental_npt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems,
+                                 float* F9) {
+    return solve_npt(h, points, ref_points, n, n_systems, 0, F9);
+}
+
+orbx_status orbx_homography_dlt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems,
+                                float* H9) {
+    return solve_npt(h, points, ref_points, n, n_systems, 1, H9);
+}
+
 }  // extern "C"
 
 namespace {

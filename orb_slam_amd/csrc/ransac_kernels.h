@@ -453,6 +453,243 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
 }
 
+// ---- the public solvers for any number of correspondences ----------------------------------------------------
+// geometry::computeFundamentalMat / computeHomographyMat (utils.cpp:61-154) accept any n; the systems are n x 9 and
+// 2n x 9.  One wavefront works on one system.  cv::JacobiSVDImpl_<float> is a chain of row-pair rotations whose
+// order cannot change, and every dot product and row norm is a double sum in index order; what IS independent is the
+// per-element work, so the 64 lanes form the products (exact in double: float x float) and rotate the row elements
+// side by side, park the products in LDS, and lane 0 adds them in index order.  At (N rows of length M, N <= 9)
+// lives in global memory, Vt and W in LDS.
+constexpr int kSvdChunk = 256;
+struct SvdShared {
+    double prod_a[kSvdChunk], prod_b[kSvdChunk];
+    double W[9], bc[2];
+    float Vt[81];
+};
+
+// sum_k x[k] * y[k], accumulated in double in index order; every lane returns the sum
+__device__ __forceinline__ double wave_dot_ordered(const float* x, const float* y, int M, SvdShared& sh) {
+    const int lane = threadIdx.x;
+    double acc = 0;
+    for (int base = 0; base < M; base += kSvdChunk) {
+        const int cnt = min(kSvdChunk, M - base);
+        for (int k = lane; k < cnt; k += 64) sh.prod_a[k] = (double)x[base + k] * y[base + k];
+        __syncthreads();
+        if (lane == 0)
+            for (int k = 0; k < cnt; k++) acc += sh.prod_a[k];
+        __syncthreads();
+    }
+    if (lane == 0) sh.bc[0] = acc;
+    __syncthreads();
+    acc = sh.bc[0];
+    __syncthreads();
+    return acc;
+}
+
+// JacobiSVDImpl_<float> on the N rows (length M) of At with Vt (N x N) accumulated in sh.Vt; on return sh.W holds
+// the sorted singular values and Vt (and, with sort_rows, At) follow the sort.  With sort_rows and M == 9 the rows
+// N .. 8 of At, and rows with a vanishing singular value, are completed to an orthonormal set as OpenCV does
+// (At then has room for 9 rows).
+__device__ void svd_rows_wave(float* At, int M, int N, bool sort_rows, SvdShared& sh) {
+    const int lane = threadIdx.x;
+    const float eps = 1.1920928955078125e-7f * 2;
+    const int max_iter = M > 30 ? M : 30;
+    for (int i = 0; i < N; i++) {
+        const double w = wave_dot_ordered(At + (size_t)i * M, At + (size_t)i * M, M, sh);
+        if (lane == 0) sh.W[i] = w;
+    }
+    for (int k = lane; k < N * N; k += 64) sh.Vt[k] = (k / N == k % N) ? 1.f : 0.f;
+    __syncthreads();
+    for (int iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (int i = 0; i < N - 1; i++)
+            for (int j = i + 1; j < N; j++) {
+                float* Ai = At + (size_t)i * M;
+                float* Aj = At + (size_t)j * M;
+                double p = wave_dot_ordered(Ai, Aj, M, sh);
+                double a = sh.W[i], b = sh.W[j];
+                if (fabs(p) <= eps * sqrt((double)a * b)) continue;  // the same decision on every lane
+                p *= 2;
+                const double beta = a - b, gamma = hypot_f64((double)p, beta);
+                float c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = (float)sqrt(delta / gamma);
+                    c = (float)(p / (gamma * s * 2));
+                } else {
+                    c = (float)sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * c * 2));
+                }
+                a = b = 0;
+                for (int base = 0; base < M; base += kSvdChunk) {
+                    const int cnt = min(kSvdChunk, M - base);
+                    for (int k = lane; k < cnt; k += 64) {
+                        const float x = Ai[base + k], y = Aj[base + k];
+                        const float t0 = c * x + s * y;
+                        const float t1 = -s * x + c * y;
+                        Ai[base + k] = t0;
+                        Aj[base + k] = t1;
+                        sh.prod_a[k] = (double)t0 * t0;
+                        sh.prod_b[k] = (double)t1 * t1;
+                    }
+                    __syncthreads();
+                    if (lane == 0)
+                        for (int k = 0; k < cnt; k++) {
+                            a += sh.prod_a[k];
+                            b += sh.prod_b[k];
+                        }
+                    __syncthreads();
+                }
+                if (lane == 0) {
+                    sh.W[i] = a;
+                    sh.W[j] = b;
+                }
+                changed = true;
+                if (lane < N) {
+                    const float x = sh.Vt[i * N + lane], y = sh.Vt[j * N + lane];
+                    sh.Vt[i * N + lane] = c * x + s * y;
+                    sh.Vt[j * N + lane] = -s * x + c * y;
+                }
+                __syncthreads();
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < N; i++) {
+        const double w = wave_dot_ordered(At + (size_t)i * M, At + (size_t)i * M, M, sh);
+        if (lane == 0) sh.W[i] = sqrt(w);
+    }
+    __syncthreads();
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < N; k++)
+            if (sh.W[j] < sh.W[k]) j = k;
+        __syncthreads();
+        if (i != j) {
+            if (lane == 0) { const double t = sh.W[i]; sh.W[i] = sh.W[j]; sh.W[j] = t; }
+            if (lane < N) { const float t = sh.Vt[i * N + lane]; sh.Vt[i * N + lane] = sh.Vt[j * N + lane]; sh.Vt[j * N + lane] = t; }
+            if (sort_rows)
+                for (int k = lane; k < M; k += 64) {
+                    const float t = At[(size_t)i * M + k];
+                    At[(size_t)i * M + k] = At[(size_t)j * M + k];
+                    At[(size_t)j * M + k] = t;
+                }
+        }
+        __syncthreads();
+    }
+    if (!sort_rows || M != 9) return;
+    if (lane == 0) {
+        // the completion of cv::JacobiSVDImpl_ (n1 = 9 rows of length 9), a few hundred operations: one lane
+        const double minval = 1.17549435082228750797e-38;  // FLT_MIN
+        unsigned long long rng = 0x12345678ull;
+        for (int i = 0; i < 9; i++) {
+            double sd = i < N ? sh.W[i] : 0;
+            for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+                const float val0 = (float)(1. / 9);
+                for (int k = 0; k < 9; k++) {
+                    rng = (unsigned long long)(unsigned)rng * 4164903690U + (unsigned)(rng >> 32);
+                    At[i * 9 + k] = ((unsigned)rng & 256) != 0 ? val0 : -val0;
+                }
+                for (int it2 = 0; it2 < 2; it2++)
+                    for (int j = 0; j < i; j++) {
+                        sd = 0;
+                        for (int k = 0; k < 9; k++) sd += At[i * 9 + k] * At[j * 9 + k];
+                        float asum = 0;
+                        for (int k = 0; k < 9; k++) {
+                            const float t = (float)(At[i * 9 + k] - sd * At[j * 9 + k]);
+                            At[i * 9 + k] = t;
+                            asum += fabsf(t);
+                        }
+                        asum = asum > eps * 100 ? 1 / asum : 0;
+                        for (int k = 0; k < 9; k++) At[i * 9 + k] *= asum;
+                    }
+                sd = 0;
+                for (int k = 0; k < 9; k++) {
+                    const float t = At[i * 9 + k];
+                    sd += (double)t * t;
+                }
+                sd = sqrt(sd);
+            }
+            const float s = (float)(sd > minval ? 1 / sd : 0.);
+            for (int k = 0; k < 9; k++) At[i * 9 + k] *= s;
+        }
+    }
+    __syncthreads();
+}
+
+// geometry::computeFundamentalMat (model 0, utils.cpp:61-103) or computeHomographyMat (model 1, :112-154) on ALL n
+// correspondences of a system: grid = systems, one wavefront each; system q reads n points from pts + q*n*2 and
+// writes out9 + q*9.  work: 9 * max(rows, 9) floats per system, rows = n or 2n.
+__global__ __launch_bounds__(64) void k_solve_npt(const float* __restrict__ pts, const float* __restrict__ ref, int n,
+                                                  int model, float* __restrict__ work, float* __restrict__ out9) {
+    __shared__ SvdShared sh;
+    const int lane = threadIdx.x, q = blockIdx.x;
+    const float2* p2 = (const float2*)(pts + (size_t)q * n * 2);
+    const float2* r2 = (const float2*)(ref + (size_t)q * n * 2);
+    const int rows = model == 0 ? n : 2 * n;
+    // cv::SVDecomp works on the matrix whose rows are the SHORTER dimension: with 9 or more equations the system
+    // is transposed (9 rows of length `rows`) and vt is the accumulated Vt; with fewer, the equations are the rows
+    // (length 9), vt is the row set itself, completed to 9 rows
+    const bool transposed = rows >= 9;
+    const int M = transposed ? rows : 9, N = transposed ? 9 : rows;
+    float* At = work + (size_t)q * 9 * (rows > 9 ? rows : 9);
+    if (!transposed)
+        for (int k = lane; k < 81; k += 64) At[k] = 0.f;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const float u1 = r2[i].x, v1 = r2[i].y, u2 = p2[i].x, v2 = p2[i].y;
+        float e[2][9];
+        if (model == 0) {
+            e[0][0] = u2 * u1; e[0][1] = u2 * v1; e[0][2] = u2;
+            e[0][3] = v2 * u1; e[0][4] = v2 * v1; e[0][5] = v2;
+            e[0][6] = u1; e[0][7] = v1; e[0][8] = 1;
+        } else {
+            e[0][0] = 0.0f; e[0][1] = 0.0f; e[0][2] = 0.0f; e[0][3] = -u1; e[0][4] = -v1; e[0][5] = -1;
+            e[0][6] = v2 * u1; e[0][7] = v2 * v1; e[0][8] = v2;
+            e[1][0] = u1; e[1][1] = v1; e[1][2] = 1; e[1][3] = 0.0f; e[1][4] = 0.0f; e[1][5] = 0.0f;
+            e[1][6] = -u2 * u1; e[1][7] = -u2 * v1; e[1][8] = -u2;
+        }
+        const int per = model == 0 ? 1 : 2;
+        for (int r = 0; r < per; r++) {
+            const int row = i * per + r;
+#pragma unroll
+            for (int cc = 0; cc < 9; cc++) {
+                if (transposed) At[(size_t)cc * M + row] = e[r][cc];
+                else At[row * 9 + cc] = e[r][cc];
+            }
+        }
+    }
+    __syncthreads();
+    svd_rows_wave(At, M, N, !transposed, sh);
+    if (lane != 0) return;
+    float v8[9];
+    for (int k = 0; k < 9; k++) v8[k] = transposed ? sh.Vt[8 * 9 + k] : At[8 * 9 + k];  // vt.row(8)
+    float* out = out9 + (size_t)q * 9;
+    if (model == 1) {
+        for (int k = 0; k < 9; k++) out[k] = v8[k];
+        return;
+    }
+    // rank-2 enforcement: SVD of the 3 x 3 matrix (worked on as its transpose), smallest singular value dropped
+    float B[9], V3[9];
+    double W3[3];
+    int perm3[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) B[j * 3 + i] = v8[i * 3 + j];
+    jacobi_sweeps<3, 3, true>(B, V3, W3);
+    svd_finish<3, 3, true, true>(B, V3, W3, perm3);
+    svd_complete<3, 3, 3>(B, W3);
+    const float w0 = (float)W3[0], w1 = (float)W3[1];
+    float U[9], D[9] = {w0, 0, 0, 0, w1, 0, 0, 0, 0.f}, UD[9], Fn[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) U[j * 3 + i] = B[i * 3 + j];
+    mul33(U, D, UD);
+    mul33(UD, V3, Fn);
+    for (int k = 0; k < 9; k++) out[k] = Fn[k];
+}
+
 constexpr int kScoreChunk = 512;    // correspondences per pair staged in LDS at a time
 constexpr int kScorePairs = 4;      // pairs a 256-hypothesis workgroup may span (iterations >= 86)
 

@@ -33,6 +33,7 @@ SYMBOLS = [
     "orbx_feeder_start_memory", "orbx_feeder_next",
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
     "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream", "orbx_matcher_set_hamming_kernel",
+    "orbx_normalize_points", "orbx_fundamental_npt", "orbx_homography_dlt",
 ]
 
 
@@ -647,6 +648,33 @@ class Ransac:
         _check(lib().orbx_triangulate_batch(self._h, len(ps) - 1, _p(K), _p(R), _p(t), _p(pts), _p(ref), _p(ps),
                                             _p(out)), "orbx_triangulate_batch")
         return out[:len(pts)]
+
+    def normalize_points(self, xy):
+        """geometry::normalizePoints on the device: (normalised n x 2, T 3 x 3)."""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros_like(xy)
+        T = np.zeros(9, np.float32)
+        _check(lib().orbx_normalize_points(self._h, _p(xy), len(xy), _p(out), _p(T)), "orbx_normalize_points")
+        return out, T.reshape(3, 3)
+
+    def _npt(self, fn, name, pts, ref):
+        pts = np.ascontiguousarray(pts, np.float32)
+        ref = np.ascontiguousarray(ref, np.float32)
+        single = pts.ndim == 2
+        pts = pts.reshape((1,) + pts.shape) if single else pts
+        ref = ref.reshape(pts.shape)
+        out = np.zeros((pts.shape[0], 9), np.float32)
+        _check(fn(self._h, _p(pts), _p(ref), pts.shape[1], pts.shape[0], _p(out)), name)
+        out = out.reshape(-1, 3, 3)
+        return out[0] if single else out
+
+    def fundamental_npt(self, pts, ref):
+        """geometry::computeFundamentalMat for n x 2 points (or systems x n x 2)."""
+        return self._npt(lib().orbx_fundamental_npt, "orbx_fundamental_npt", pts, ref)
+
+    def homography_dlt(self, pts, ref):
+        """geometry::computeHomographyMat for n x 2 points (or systems x n x 2)."""
+        return self._npt(lib().orbx_homography_dlt, "orbx_homography_dlt", pts, ref)
 
     def fh(self, pts, ref, sets8, sigma=1.0):
         pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)

@@ -712,6 +712,68 @@ def test_ransac_result_identical(oracle, ransac, utils_points):
         ransac.fh(pts, ref, bad, 1.0)
 
 
+def _same_bits(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    nan = np.isnan(a)
+    return np.array_equal(nan, np.isnan(b)) and np.array_equal(a.view(np.uint32)[~nan], b.view(np.uint32)[~nan])
+
+
+def test_public_solvers_reference_kat_through_hip(oracle, ransac, utils_points):
+    """src/tests/geometry/utils_tests.cpp:71-121 with the three public solvers of geometry/utils.h running on the GPU:
+    the reference's own tolerances against its golden matrices (79 pairs, the m >= n path of cv::SVDecomp), and bit
+    equality with the oracle."""
+    pts, ref = utils_points["points"], utils_points["ref_points"]
+    pn, T = ransac.normalize_points(pts)
+    rn, rT = ransac.normalize_points(ref)
+    opn, oT = oracle.normalize_points(pts)
+    orn, orT = oracle.normalize_points(ref)
+    assert _same_bits(pn, opn) and _same_bits(T, oT) and _same_bits(rn, orn) and _same_bits(rT, orT)
+    Fn = ransac.fundamental_npt(pn, rn)
+    assert _same_bits(Fn, oracle.fundamental_8pt(pn, rn))
+    F = T.T.astype(np.float64) @ Fn.astype(np.float64) @ rT.astype(np.float64)
+    assert np.linalg.norm(F / F[2, 2] - utils_points["F_gold"]) <= 1e-3          # utils_tests.cpp:97
+    Hn = ransac.homography_dlt(pn, rn)
+    assert _same_bits(Hn, oracle.homography_dlt(pn, rn))
+    H = np.linalg.inv(T.astype(np.float64)) @ Hn.astype(np.float64) @ rT.astype(np.float64)
+    assert np.linalg.norm(H / H[2, 2] - utils_points["H_gold"]) <= 1.0           # utils_tests.cpp:120
+
+
+def test_public_solvers_any_point_count_bit_exact(oracle, ransac):
+    """computeFundamentalMat / computeHomographyMat / normalizePoints for every shape of system cv::SVDecomp
+    distinguishes: fewer equations than unknowns (completion by the seeded Gram-Schmidt), exactly 8 and 9, many (more
+    than one LDS chunk of products), rank-deficient inputs, and several systems per call."""
+    rng = np.random.default_rng(31)
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 10, 33, 79, 300, 1000):
+        pts, ref = _two_view(rng, max(n, 8), 0)
+        pts, ref = pts[:n].copy(), ref[:n].copy()
+        pn, T = ransac.normalize_points(pts)
+        opn, oT = oracle.normalize_points(pts)
+        assert _same_bits(pn, opn) and _same_bits(T, oT), n
+        rn, _ = oracle.normalize_points(ref)
+        if n == 1:  # a single point normalises to NaN (0 / 0): feed the solvers the raw points instead
+            opn, rn = pts, ref
+        assert _same_bits(ransac.fundamental_npt(opn, rn), oracle.fundamental_8pt(opn, rn)), n
+        assert _same_bits(ransac.homography_dlt(opn, rn), oracle.homography_dlt(opn, rn)), n
+    x = rng.uniform(0, 640, 40).astype(np.float32)
+    collinear = np.stack([x, 0.5 * x + 20], 1).astype(np.float32)
+    lattice = np.stack(np.meshgrid(np.arange(6) * 40.0, np.arange(6) * 30.0), -1).reshape(-1, 2).astype(np.float32)
+    for pts, ref in ((collinear, collinear[::-1].copy()), (lattice, lattice), (lattice, lattice * 2 + 3),
+                     (np.zeros((12, 2), np.float32), np.zeros((12, 2), np.float32))):
+        assert _same_bits(ransac.fundamental_npt(pts, ref), oracle.fundamental_8pt(pts, ref))
+        assert _same_bits(ransac.homography_dlt(pts, ref), oracle.homography_dlt(pts, ref))
+    many = [_two_view(rng, 50, 5) for _ in range(70)]
+    P = np.stack([m[0] for m in many])
+    R = np.stack([m[1] for m in many])
+    F = ransac.fundamental_npt(P, R)
+    H = ransac.homography_dlt(P, R)
+    for q in range(len(many)):
+        assert _same_bits(F[q], oracle.fundamental_8pt(P[q], R[q])), q
+        assert _same_bits(H[q], oracle.homography_dlt(P[q], R[q])), q
+    with pytest.raises(orbx.OrbxError):
+        ransac.fundamental_npt(np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32))
+
+
 def test_ransac_batch_equals_single(oracle, ransac):
     import torch
     rng = np.random.default_rng(23)
