@@ -19,7 +19,7 @@ namespace geometry
 class ORBExtractor
 {
 public:
-    ORBExtractor(const ros::NodeHandle& nh, int max_width = 1920, int max_height = 1080, int device = 0): nh_(nh) {
+    ORBExtractor(const ros::NodeHandle& nh, int reserve_width = 640, int reserve_height = 480, int device = 0): nh_(nh) {
         std::string prefix = "orb_slam/orb_extractor/";
         // same keys and defaults as the reference (orb_extractor.h:29-37)
         nh_.param<int>(prefix + "n_key_points", n_key_points_, 8000);
@@ -35,9 +35,11 @@ public:
             n_key_points_, scale_factor_, level_pyramid_, edge_threshold_, first_level_, wta_k_, patch_size_,
             score_threshold_};
         handle_ = orbx_compat::PerThreadHandle<orbx_extractor>(
-            [p, max_width, max_height, device]() {
+            // the two sizes are what the handle reserves up front; an image of any other size makes it regrow
+            [p, reserve_width, reserve_height, device]() {
                 orbx_extractor* h = nullptr;
-                orbx_compat::check(orbx_extractor_create(&p, max_width, max_height, 1, device, &h), "ORBExtractor");
+                orbx_compat::check(
+                    orbx_extractor_create(&p, reserve_width, reserve_height, 1, device, &h), "ORBExtractor");
                 return h;
             },
             orbx_extractor_destroy);
@@ -70,17 +72,21 @@ public:
     {
         key_points.clear();
         if (image.empty()) return; // cv::ORB returns silently on an empty image
-        int capacity = 4 * n_key_points_ + 4096, count = 0;
+        // the library writes into a buffer of this thread that is kept from call to call (ties can push the count
+        // past n_key_points, so it starts with room to spare and grows when a frame needs more)
+        static thread_local std::vector<orbx_keypoint> found;
+        if (found.size() < (size_t)n_key_points_ + 1024) found.resize((size_t)n_key_points_ + 1024);
+        int count = 0;
         for (;;) {
-            key_points.resize(capacity);
             orbx_status s = orbx_detect(
                 handle_.get(), image.data, image.cols, image.rows, (int)image.step, image.channels(),
-                reinterpret_cast<orbx_keypoint*>(key_points.data()), capacity, &count);
-            if (s == ORBX_CAPACITY && count > capacity) { capacity = count; continue; }
+                found.data(), (int)found.size(), &count);
+            if (s == ORBX_CAPACITY && (size_t)count > found.size()) { found.resize(count); continue; }
             orbx_compat::check(s, "ORBExtractor::detect");
             break;
         }
         key_points.resize(count);
+        if (count > 0) std::memcpy(static_cast<void*>(key_points.data()), found.data(), (size_t)count * sizeof(orbx_keypoint));
     }
 
     /**

@@ -181,10 +181,14 @@ inline void check(orbx_status s, const char* where) {
  * One C-ABI handle per calling thread behind a facade object.  The reference keeps ONE ORBExtractor and ONE
  * ORBMatcher in static members (include/orb_slam/frame.h:520-522, map_point.h:240-241) and calls them from the
  * tracker thread and the local-mapper thread at the same time (src/tracker.cpp:310, src/local_mapping/
- * local_mapper.cpp:277,462,480); an orbx handle owns one stream and one set of device buffers and is not
- * re-entrant.  get() hands every thread its own handle (created on the thread's first call), so concurrent calls
- * through one facade object never share device state and never wait for each other.  The state lives behind a
- * shared_ptr: copies of a facade object share the pool, as copies of the reference's classes share their cv::Ptr.
+ * local_mapper.cpp:277,462,480); an orbx handle owns one stream and one set of device buffers and serves one call
+ * at a time.  get() hands every thread its own handle, so concurrent calls through one facade object never share
+ * device state and never wait for each other.  A handle is lent to a thread for the thread's lifetime: when the
+ * thread ends, its handles go back to the idle list of the object they belong to and the next new thread takes one
+ * from there, so a process that calls the facade from short-lived threads (pools, per-request workers) holds as many
+ * handles as it ever had threads inside the facade at once, not one per thread ever started.  The state lives
+ * behind a shared_ptr: copies of a facade object share the pool, as copies of the reference's classes share their
+ * cv::Ptr; the handles are destroyed with the last copy.
  */
 template <typename H>
 class PerThreadHandle {
@@ -197,23 +201,59 @@ public:
     }
     H* get() const {
         const std::thread::id id = std::this_thread::get_id();
-        std::lock_guard<std::mutex> lock(state_->mutex);
-        auto it = state_->handles.find(id);
-        if (it == state_->handles.end())
-            it = state_->handles.emplace(id, std::shared_ptr<H>(state_->make(), state_->destroy)).first;
-        return it->second.get();
+        H* h = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(state_->mutex);
+            auto it = state_->lent.find(id);
+            if (it != state_->lent.end()) return it->second;
+            if (!state_->idle.empty()) {
+                h = state_->idle.back();
+                state_->idle.pop_back();
+            } else {
+                h = state_->make();
+            }
+            state_->lent.emplace(id, h);
+        }
+        leases().states.push_back(state_);
+        return h;
     }
+    /* handles in existence (lent + idle) */
     size_t size() const {
         std::lock_guard<std::mutex> lock(state_->mutex);
-        return state_->handles.size();
+        return state_->lent.size() + state_->idle.size();
     }
 private:
     struct State {
         std::mutex mutex;
         std::function<H*()> make;
         void (*destroy)(H*) = nullptr;
-        std::map<std::thread::id, std::shared_ptr<H>> handles;
+        std::map<std::thread::id, H*> lent;
+        std::vector<H*> idle;
+        ~State() {
+            for (auto& kv : lent) destroy(kv.second);
+            for (H* h : idle) destroy(h);
+        }
     };
+    /* what the calling thread has borrowed; returned when the thread ends */
+    struct Leases {
+        std::vector<std::weak_ptr<State>> states;
+        ~Leases() {
+            const std::thread::id id = std::this_thread::get_id();
+            for (auto& w : states)
+                if (std::shared_ptr<State> s = w.lock()) {
+                    std::lock_guard<std::mutex> lock(s->mutex);
+                    auto it = s->lent.find(id);
+                    if (it != s->lent.end()) {
+                        s->idle.push_back(it->second);
+                        s->lent.erase(it);
+                    }
+                }
+        }
+    };
+    static Leases& leases() {
+        static thread_local Leases l;
+        return l;
+    }
     std::shared_ptr<State> state_;
 };
 }  // namespace orbx_compat

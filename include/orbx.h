@@ -6,7 +6,9 @@
  * Conventions
  *  - plain pointers and sizes only; nothing is thrown across this boundary; every call returns an orbx_status.
  *  - outputs are caller-allocated with an explicit capacity; overflow is reported (ORBX_CAPACITY), never truncated.
- *  - handles own device buffers and one HIP stream; calls on one handle must not overlap, different handles may.
+ *  - handles own device buffers and one HIP stream and serve one call at a time: a call that arrives from a second
+ *    thread while one is running returns ORBX_BUSY and touches nothing (give every thread its own handle; calls on
+ *    different handles run side by side).
  *  - pointers are HOST pointers unless the parameter name starts with d_ (device pointer on the handle's GPU).
  *  - orbx_keypoint / orbx_match are layout-identical to cv::KeyPoint / cv::DMatch, so std::vector storage
  *    of the reference's callers can be passed without copies.
@@ -26,7 +28,8 @@ typedef enum {
     ORBX_BAD_ARG = 1,
     ORBX_CAPACITY = 2,
     ORBX_DEVICE = 3,
-    ORBX_UNSUPPORTED = 4
+    ORBX_UNSUPPORTED = 4,
+    ORBX_BUSY = 5 /* the handle is serving a call of another thread */
 } orbx_status;
 
 typedef struct { float x, y, size, angle, response; int32_t octave, class_id; } orbx_keypoint; /* == cv::KeyPoint */
@@ -56,9 +59,10 @@ int orbx_device_count(void);
 
 /* ------------------------------------------------------------------ extraction ------------------------------ */
 
-/* Replaces ORBExtractor::ORBExtractor (orb_extractor.h:28-81): validates the parameters, builds the pyramid
-   geometry and allocates device buffers for images up to max_width x max_height and batches up to max_batch
-   frames on GPU `device`. */
+/* Replaces ORBExtractor::ORBExtractor (orb_extractor.h:28-81): validates the parameters and reserves device
+   buffers for images of max_width x max_height on GPU `device`; batches hold at most max_batch frames.
+   max_width / max_height are a reservation, not a limit: a larger image (up to 16384 x 16384) makes the buffers
+   grow at that call, as cv::ORB takes whatever size it is handed. */
 orbx_status orbx_extractor_create(const orbx_extractor_params* params, int max_width, int max_height,
                                   int max_batch, int device, orbx_extractor** out);
 void orbx_extractor_destroy(orbx_extractor* h);
@@ -80,9 +84,9 @@ orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int 
    receives *count rows of 32 bytes.
    MonoFrame::extractFeatures calls detect and then compute on the same image (src/mono_frame.cpp:75,102), where
    cv::ORB builds the pyramid twice.  Here the handle remembers the image of its last detect / compute (address,
-   geometry and a hash of every (height / 48)-th row) and a compute on that image finds the upload and the pyramid
-   still on the device.  A caller that rewrites pixels of the same buffer between the two calls in rows the hash
-   does not sample must switch the reuse off (orbx_extractor_set_image_cache); results are identical either way. */
+   geometry and a hash of every pixel) and a compute on that image finds the upload and the pyramid still on the
+   device; any change of a pixel between the two calls makes the compute start from the new pixels.  Results are
+   identical with the reuse switched off (orbx_extractor_set_image_cache). */
 orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
                          orbx_keypoint* keypoints, int* count, uint8_t* descriptors);
 
@@ -104,8 +108,9 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
    candidate list that overflowed) and the batch was finished inside this call - by further device passes, or by the
    host selection for an overflowed list: the device results are now the final ones, and whatever consumed them
    before has to run again.  A batch
-   that was never finished is waited for and dropped by the next call on the handle.  No counterpart in the
-   reference (its extraction is synchronous). */
+   that was never finished is waited for and dropped by the next call on the handle; a finish that arrives after
+   that returns ORBX_BAD_ARG (orbx_last_error() says why) and writes nothing.  No counterpart in the reference (its
+   extraction is synchronous). */
 orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redone);
 
 /* Switches the reuse of the uploaded image and its pyramid between orbx_detect and orbx_compute (default on). */
@@ -364,15 +369,17 @@ orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const fl
                                  float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,
                                  float* d_scores, int32_t* d_best_iteration);
 
-/* orbx_ransac_fh_batch for callers that cannot allocate device memory while they run (code under HIP graph capture,
-   tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
-   results bit for bit; the intermediate arrays (normalised points, every hypothesis and its score) live in a
-   fixed device array of about 5.9 MB that each GPU the library runs on holds until the process ends, and the call
-   makes no hipMalloc / hipFree.  Limits per call: n_pairs <= 1024, n_pairs * iterations <= 32768,
-   n_pairs * n <= 131072; beyond them ORBX_CAPACITY is returned (orbx_last_error() names the limits) and nothing
-   runs.  Every call on a GPU shares that GPU's array, whichever handle it goes through: calls that overlap on one
-   GPU race, so run them one after the other (one stream, or an event between them).  The array keeps the last
-   call's contents; the call clears the words that must start at zero itself. */
+/* orbx_ransac_fh_batch for callers that cannot allocate device memory while they run (tight serving loops,
+   harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit; the
+   intermediate arrays (normalised points, every hypothesis and its score) live in a fixed device array of about
+   5.9 MB that each GPU the library runs on holds until the process ends, and the call makes no hipMalloc / hipFree
+   (nor any other allocating call: its events exist since orbx_ransac_create).  Limits per call: n_pairs <= 1024,
+   n_pairs * iterations <= 32768, n_pairs * n <= 131072; beyond them ORBX_CAPACITY is returned (orbx_last_error()
+   names the limits) and nothing runs.  Every call on a GPU shares that GPU's array, whichever handle it goes
+   through: the library orders such calls on the device (each waits for an event the previous one recorded), so two
+   handles or two streams never overlap inside the array - they take turns.  The array keeps the last call's
+   contents; the call clears the words that must start at zero itself.  Not exercised under HIP stream capture (the
+   call records timing events and forks onto a second stream of the handle). */
 orbx_status orbx_ransac_fh_batch_static(orbx_ransac* h, const float* d_points, const float* d_ref_points, int n,
                                         const uint32_t* d_sets8, int iterations, int n_pairs, double sigma,
                                         float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,

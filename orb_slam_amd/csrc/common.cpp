@@ -22,6 +22,7 @@ const char* orbx_status_string(orbx_status s) {
         case ORBX_CAPACITY: return "capacity exceeded";
         case ORBX_DEVICE: return "device error";
         case ORBX_UNSUPPORTED: return "unsupported";
+        case ORBX_BUSY: return "handle busy";
     }
     return "unknown";
 }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,40 @@ void set_last_error_text(const char* text);
         orbx_status s__ = (expr);             \
         if (s__ != ORBX_OK) return s__;       \
     } while (0)
+
+// A handle owns one stream and one set of buffers and serves one call at a time.  Every entry point passes this
+// gate first: a second thread that arrives while a call is running gets ORBX_BUSY instead of racing on the buffers.
+// The thread that holds the gate may re-enter (entry points call each other).
+struct CallGate {
+    std::atomic<uintptr_t> owner{0};
+    int depth = 0;
+};
+class CallGuard {
+public:
+    explicit CallGuard(CallGate& g) : gate_(g) {
+        static thread_local char tag;
+        const uintptr_t me = (uintptr_t)&tag;
+        uintptr_t free_slot = 0;
+        entered_ = gate_.owner.load(std::memory_order_relaxed) == me ||
+                   gate_.owner.compare_exchange_strong(free_slot, me, std::memory_order_acquire);
+        if (entered_) gate_.depth++;
+    }
+    ~CallGuard() {
+        if (entered_ && --gate_.depth == 0) gate_.owner.store(0, std::memory_order_release);
+    }
+    bool entered() const { return entered_; }
+private:
+    CallGate& gate_;
+    bool entered_;
+};
+#define ORBX_ENTER(h)                                                                                          \
+    if (!(h)) return ORBX_BAD_ARG;                                                                             \
+    ::orbx::CallGuard call_guard__((h)->gate);                                                                 \
+    if (!call_guard__.entered()) {                                                                             \
+        ::orbx::set_last_error_text("the handle is serving a call of another thread (one call at a time per "  \
+                                    "handle: give every thread its own)");                                     \
+        return ORBX_BUSY;                                                                                      \
+    }
 
 // Device allocation that remembers its size; freed by the owning handle.
 template <typename T>

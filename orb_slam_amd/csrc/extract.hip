@@ -27,6 +27,7 @@ inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
 }  // namespace
 
 struct orbx_extractor {
+    CallGate gate;  // one call at a time (ORBX_ENTER)
     orbx_extractor_params prm;
     int device = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
@@ -117,7 +118,8 @@ struct orbx_extractor {
         int width = 0, height = 0, stride = 0, channels = 0, capacity = 0;
     } pending;
     hipEvent_t ev_done = nullptr;
-    std::vector<int32_t> last_counts;  // keypoints per frame of the last finished batch
+    std::vector<int32_t> last_counts;  // keypoints per frame of the most recent batch, once it has finished
+    bool batch_dropped = false;        // a deferred batch was waited for and dropped by a later call, never finished
 
     StageTimer timer;
     float last_ms[ST_COUNT] = {};
@@ -347,11 +349,13 @@ struct BlurForkGuard {
     ~BlurForkGuard() { join_blur_fork(h); }
 };
 
-// Fingerprint of a host image for the detect -> compute pyramid reuse: its address, geometry and a hash of every
-// h/48-th row (about 2 % of the bytes, a few microseconds; hashing everything would cost what the reuse saves).
+// Fingerprint of a host image for the detect -> compute pyramid reuse: its address, geometry and a hash of EVERY
+// pixel (four independent multiply chains over 32 bytes at a time: some 40 microseconds for a VGA colour frame, against
+// the upload and the pyramid launches the reuse saves).  A sampled hash would let a caller who rewrites part of the
+// buffer between two calls get descriptors of the old pixels; cv::ORB::compute has no such precondition.
 uint64_t sample_rows(const uint8_t* image, int w, int hgt, int stride, int ch) {
     const size_t row_bytes = (size_t)w * ch;
-    const int step = std::max(1, hgt / 48);
+    const int step = 1;
     uint64_t acc[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
     auto row = [&](int y) {
         const uint8_t* p = image + (size_t)y * stride;
@@ -388,6 +392,8 @@ void remember_image(orbx_extractor* h, const uint8_t* image, int w, int hgt, int
 orbx_status drain_pending(orbx_extractor* h) {
     if (!h->pending.active) return ORBX_OK;
     h->pending.active = false;
+    h->batch_dropped = true;
+    h->last_counts.clear();
     ORBX_HIP(hipEventSynchronize(h->ev_done));
     return ORBX_OK;
 }
@@ -654,7 +660,7 @@ orbx_status check_image_args(const orbx_extractor* h, const void* image, int w, 
     if (!h || !image) return ORBX_BAD_ARG;
     if (ch != 1 && ch != 3) return ORBX_BAD_ARG;
     if (w <= 0 || hgt <= 0 || stride < w * ch) return ORBX_BAD_ARG;
-    if (w > h->max_w || hgt > h->max_h) return ORBX_CAPACITY;
+    if (w > 16384 || hgt > 16384) return ORBX_UNSUPPORTED;  // tile and strip origins are 16-bit
     return ORBX_OK;
 }
 
@@ -767,6 +773,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
 }
 
 orbx_status orbx_extractor_set_stream(orbx_extractor* h, void* hip_stream) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return ORBX_OK;
@@ -782,6 +789,7 @@ orbx_status orbx_extractor_scale_tables(const orbx_extractor* h, float* sf, floa
 orbx_status orbx_extractor_layout(const orbx_extractor* hc, int width, int height, int* atlas_w, int* atlas_h,
                                   int32_t* rects, float* scales) {
     orbx_extractor* h = const_cast<orbx_extractor*>(hc);
+    ORBX_ENTER(h);
     if (!h || width <= 0 || height <= 0) return ORBX_BAD_ARG;
     ORBX_HIP(hipSetDevice(h->device));
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
@@ -800,6 +808,7 @@ orbx_status orbx_extractor_layout(const orbx_extractor* hc, int width, int heigh
 }
 
 orbx_status orbx_extractor_read_plane(orbx_extractor* h, int frame, int what, uint8_t* out, size_t out_bytes) {
+    ORBX_ENTER(h);
     if (!h || !out || frame < 0 || frame >= std::max(h->last_frames, 1)) return ORBX_BAD_ARG;
     if (out_bytes < h->atlas_bytes) return ORBX_CAPACITY;
     ORBX_HIP(hipSetDevice(h->device));
@@ -851,6 +860,7 @@ int orbx_extractor_last_timings(const orbx_extractor* h, float* ms, int cap) {
 
 orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
                         orbx_keypoint* keypoints, int capacity, int* count) {
+    ORBX_ENTER(h);
     if (!count || capacity < 0 || (capacity > 0 && !keypoints)) return ORBX_BAD_ARG;
     *count = 0;
     ORBX_TRY(check_image_args(h, image, width, height, stride, channels));
@@ -877,6 +887,7 @@ orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int 
 
 orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int height, int stride, int channels,
                          orbx_keypoint* keypoints, int* count, uint8_t* descriptors) {
+    ORBX_ENTER(h);
     if (!count || *count < 0 || (*count > 0 && (!keypoints || !descriptors))) return ORBX_BAD_ARG;
     ORBX_TRY(check_image_args(h, image, width, height, stride, channels));
     int n = *count;
@@ -1067,11 +1078,14 @@ extern "C" {
 orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n_frames, size_t frame_stride,
                                int width, int height, int stride, int channels, orbx_keypoint* keypoints,
                                int capacity, int32_t* counts, uint8_t* descriptors) {
+    ORBX_ENTER(h);
     ORBX_TRY(check_image_args(h, d_images, width, height, stride, channels));
     if (n_frames <= 0 || capacity <= 0 || frame_stride < (size_t)stride * height) return ORBX_BAD_ARG;
     if (n_frames > h->max_batch) return ORBX_CAPACITY;
     ORBX_HIP(hipSetDevice(h->device));
     ORBX_TRY(drain_pending(h));
+    h->batch_dropped = false;  // this batch is now the most recent one
+    h->last_counts.clear();
     h->cached_image.valid = false;
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
     ORBX_TRY(ensure_buffers(h, n_frames));
@@ -1234,10 +1248,16 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
 }
 
 orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redone) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     if (redone) *redone = 0;
     if (!h->pending.active) {
-        // the batch was completed inside orbx_extract_batch (host selection): only the counts are left to hand over
+        if (h->batch_dropped) {
+            set_last_error_text("orbx_extractor_finish: the deferred batch was dropped by a later call on the handle "
+                                "before it was finished; there is nothing to report");
+            return ORBX_BAD_ARG;
+        }
+        // the most recent batch was completed inside orbx_extract_batch: only its counts are left to hand over
         if (counts && !h->last_counts.empty()) std::memcpy(counts, h->last_counts.data(), sizeof(int32_t) * h->last_counts.size());
         return ORBX_OK;
     }
@@ -1276,12 +1296,14 @@ orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redon
 }
 
 orbx_status orbx_extractor_set_blur_fork(orbx_extractor* h, int enabled) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->fork_blur = enabled != 0;
     return ORBX_OK;
 }
 
 orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera* camera, const orbx_grid* grid) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     if (grid && (grid->grid_cols <= 0 || grid->grid_rows <= 0 || grid->grid_size_x <= 0 || grid->grid_size_y <= 0 ||
                  (long long)grid->grid_cols * grid->grid_rows > (1 << 20)))
@@ -1295,6 +1317,7 @@ orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera*
 }
 
 orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->image_cache_enabled = enabled != 0;
     h->cached_image.valid = false;
@@ -1302,12 +1325,14 @@ orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled) {
 }
 
 orbx_status orbx_extractor_set_device_select(orbx_extractor* h, int enabled) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->device_select = enabled != 0;
     return ORBX_OK;
 }
 
 orbx_status orbx_extractor_device_grid(orbx_extractor* h, const int32_t** d_cell_start, const int32_t** d_cell_items) {
+    ORBX_ENTER(h);
     if (!h || !h->has_grid) return ORBX_BAD_ARG;
     if (d_cell_start) *d_cell_start = h->d_cell_start.p;
     if (d_cell_items) *d_cell_items = h->d_cell_items.p;
@@ -1316,6 +1341,7 @@ orbx_status orbx_extractor_device_grid(orbx_extractor* h, const int32_t** d_cell
 
 orbx_status orbx_extractor_device_results(orbx_extractor* h, const orbx_keypoint** d_keypoints,
                                           const uint8_t** d_descriptors, const int32_t** d_counts, int* kp_capacity) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     if (d_keypoints) *d_keypoints = h->d_kp.p;
     if (d_descriptors) *d_descriptors = h->d_desc.p;

@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void k_bf_hamming(const uint8_t* __restrict__ 
     // train set, p = qs * t_sets + ts
     const int p = blockIdx.z;
     const int qs = t_sets > 0 ? p / t_sets : p, ts = t_sets > 0 ? p - qs * t_sets : p;
-    const int nq = nq_arr ? nq_arr[qs] : nq_const;
-    const int nt = nt_arr ? nt_arr[ts] : nt_const;
+    // the per-set counts come from device memory another kernel wrote: never beyond the capacity the buffers were
+    // sized for (nq_const / nt_const), never negative
+    const int nq = nq_arr ? min(max(nq_arr[qs], 0), nq_const) : nq_const;
+    const int nt = nt_arr ? min(max(nt_arr[ts], 0), nt_const) : nt_const;
     const int t0 = blockIdx.y * chunk;
     const int t1 = min(nt, t0 + chunk);
     if (blockIdx.x * kHamBlockQ >= nq || t0 >= t1) return;
@@ -163,8 +165,10 @@ __global__ __launch_bounds__(256, 2) void k_bf_hamming_mfma(const uint8_t* __res
                                                          size_t best_stride, int t_sets) {
     const int p = blockIdx.z;
     const int qs = t_sets > 0 ? p / t_sets : p, ts = t_sets > 0 ? p - qs * t_sets : p;
-    const int nq = nq_arr ? nq_arr[qs] : nq_const;
-    const int nt = nt_arr ? nt_arr[ts] : nt_const;
+    // the per-set counts come from device memory another kernel wrote: never beyond the capacity the buffers were
+    // sized for (nq_const / nt_const), never negative
+    const int nq = nq_arr ? min(max(nq_arr[qs], 0), nq_const) : nq_const;
+    const int nt = nt_arr ? min(max(nt_arr[ts], 0), nt_const) : nt_const;
     const int t0 = blockIdx.y * chunk;
     const int t1 = min(nt, t0 + chunk);
     if (blockIdx.x * kMfmaBlockQ >= nq || t0 >= t1) return;
@@ -308,7 +312,7 @@ __global__ void k_unpack_best(const unsigned long long* __restrict__ best, size_
                               const int* __restrict__ nq_arr, int nq_const, int32_t* __restrict__ idx,
                               int32_t* __restrict__ dist, size_t out_stride, int t_sets) {
     const int p = blockIdx.y;
-    const int nq = nq_arr ? nq_arr[t_sets > 0 ? p / t_sets : p] : nq_const;
+    const int nq = nq_arr ? min(max(nq_arr[t_sets > 0 ? p / t_sets : p], 0), nq_const) : nq_const;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const unsigned long long k = best[(size_t)p * best_stride + i];
@@ -1771,6 +1775,7 @@ __global__ __launch_bounds__(256) void k_fuse_search(FuseArgs A) {
 }  // namespace
 
 struct orbx_matcher {
+    CallGate gate;  // one call at a time (ORBX_ENTER)
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     DevBuf<uint8_t> d_q, d_t, d_flags;
@@ -1861,12 +1866,14 @@ void orbx_matcher_destroy(orbx_matcher* h) {
 }
 
 orbx_status orbx_matcher_set_stream(orbx_matcher* h, void* hip_stream) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return ORBX_OK;
 }
 
 orbx_status orbx_matcher_set_hamming_kernel(orbx_matcher* h, int kind) {
+    ORBX_ENTER(h);
     if (!h || (kind != 0 && kind != 1)) return ORBX_BAD_ARG;
     h->hamming_kernel = kind;
     return ORBX_OK;
@@ -1876,6 +1883,7 @@ orbx_status orbx_match_hamming_batch(orbx_matcher* h, const uint8_t* d_query, co
                                      size_t query_stride, const uint8_t* d_train, const int32_t* d_n_train,
                                      size_t train_stride, int n_pairs, int max_query, int max_train,
                                      int32_t* d_train_idx, int32_t* d_distance, size_t out_stride) {
+    ORBX_ENTER(h);
     return hamming_sets(h, d_query, d_n_query, query_stride, d_train, d_n_train, train_stride, n_pairs, 0, max_query,
                         max_train, d_train_idx, d_distance, out_stride);
 }
@@ -1884,6 +1892,7 @@ orbx_status orbx_match_hamming_cross(orbx_matcher* h, const uint8_t* d_query, co
                                      size_t query_stride, int n_query_sets, const uint8_t* d_train,
                                      const int32_t* d_n_train, size_t train_stride, int n_train_sets, int max_query,
                                      int max_train, int32_t* d_train_idx, int32_t* d_distance, size_t out_stride) {
+    ORBX_ENTER(h);
     if (n_query_sets <= 0 || n_train_sets <= 0 || (long long)n_query_sets * n_train_sets > 65535) return ORBX_BAD_ARG;
     return hamming_sets(h, d_query, d_n_query, query_stride, d_train, d_n_train, train_stride,
                         n_query_sets * n_train_sets, n_train_sets, max_query, max_train, d_train_idx, d_distance,
@@ -1892,6 +1901,7 @@ orbx_status orbx_match_hamming_cross(orbx_matcher* h, const uint8_t* d_query, co
 
 orbx_status orbx_match_hamming(orbx_matcher* h, const uint8_t* query, int n_query, const uint8_t* train, int n_train,
                                int32_t* train_idx, int32_t* distance) {
+    ORBX_ENTER(h);
     if (!h || n_query < 0 || n_train < 0) return ORBX_BAD_ARG;
     if (n_query == 0) return ORBX_OK;
     if (!query || !train_idx || !distance || (n_train > 0 && !train)) return ORBX_BAD_ARG;
@@ -1914,6 +1924,7 @@ orbx_status orbx_match_hamming(orbx_matcher* h, const uint8_t* query, int n_quer
 orbx_status orbx_match_radius(orbx_matcher* h, const orbx_keypoint* kp, int n, const orbx_keypoint* ref_kp, int n_ref,
                               const uint8_t* desc, const uint8_t* ref_desc, double max_pixel_dist, orbx_match* matches,
                               int* count) {
+    ORBX_ENTER(h);
     if (!h || !count || n < 0 || n_ref < 0) return ORBX_BAD_ARG;
     *count = 0;
     if (n == 0 || n_ref == 0) return ORBX_OK;
@@ -2079,6 +2090,7 @@ orbx_status orbx_match_projection_frame(orbx_matcher* h, const orbx_grid* g, con
                                         const uint8_t* ref_descriptors, const float* scale_factors, int n_levels,
                                         int level_mode, float radius, int check_orientation, orbx_match* matches,
                                         int* count) {
+    ORBX_ENTER(h);
     return run_projection(h, 0, g, cell_start, cell_items, keypoints, n, descriptors, ref_keypoints, n_ref,
                           ref_has_point, proj_xy, proj_z, nullptr, nullptr, ref_descriptors, scale_factors, n_levels,
                           level_mode, radius, 0.f, check_orientation, matches, count);
@@ -2093,6 +2105,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
                                               const float* d_proj_z, const float* scale_factors, int n_levels,
                                               int level_mode, float radius, int check_orientation,
                                               int32_t* d_matched, int32_t* d_distance, int32_t* d_n_matches) {
+    ORBX_ENTER(h);
     if (!h || !g || n_pairs <= 0 || !d_frame_index || !d_ref_index || !d_keypoints || !d_descriptors || !d_counts ||
         !d_cell_start || !d_cell_items || !d_proj_xy || !scale_factors || !d_matched || !d_distance)
         return ORBX_BAD_ARG;
@@ -2183,6 +2196,7 @@ orbx_status orbx_match_projection_points_batch(orbx_matcher* h, const orbx_grid*
                                                const float* scale_factors, int n_levels, float radius,
                                                float nn_ratio, int32_t* d_matched, int32_t* d_distance,
                                                int32_t* d_n_matches) {
+    ORBX_ENTER(h);
     if (!h || !g || n_pairs <= 0 || !d_frame_index || !d_keypoints || !d_descriptors || !d_counts || !d_cell_start ||
         !d_cell_items || !d_n_points || !d_in_view || !d_proj_xy || !d_pred_level || !d_view_cos ||
         !d_point_descriptors || !scale_factors || !d_matched || !d_distance)
@@ -2249,6 +2263,7 @@ orbx_status orbx_match_projection_points(orbx_matcher* h, const orbx_grid* g, co
                                          const float* proj_xy, const int32_t* pred_level, const float* view_cos,
                                          const uint8_t* point_descriptors, const float* scale_factors, int n_levels,
                                          float radius, float nn_ratio, orbx_match* matches, int* count) {
+    ORBX_ENTER(h);
     return run_projection(h, 1, g, cell_start, cell_items, keypoints, n, descriptors, nullptr, n_points, in_view,
                           proj_xy, nullptr, pred_level, view_cos, point_descriptors, scale_factors, n_levels, 0,
                           radius, nn_ratio, 0, matches, count);
@@ -2334,6 +2349,7 @@ extern "C" {
 
 orbx_status orbx_match_bow_batch(orbx_matcher* h, const orbx_bow_pair* pairs, int n_pairs, int low_threshold,
                                  float nn_ratio, int check_orientation, orbx_match* matches, int* counts) {
+    ORBX_ENTER(h);
     if (!h || n_pairs < 0) return ORBX_BAD_ARG;
     if (n_pairs == 0) return ORBX_OK;
     if (!pairs || !counts) return ORBX_BAD_ARG;
@@ -2432,6 +2448,7 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
                            const int32_t* ref_node_start, const int32_t* ref_node_items, int n_ref_nodes,
                            int low_threshold, float nn_ratio, int check_orientation, orbx_match* matches,
                            int* count) {
+    ORBX_ENTER(h);
     if (!h || !count) return ORBX_BAD_ARG;
     *count = 0;
     const orbx_bow_pair q{keypoints, n, descriptors, ref_keypoints, n_ref, ref_descriptors, ref_has_point,
@@ -2443,6 +2460,7 @@ orbx_status orbx_match_bow(orbx_matcher* h, const orbx_keypoint* keypoints, int 
 orbx_status orbx_match_epipolar_batch(orbx_matcher* h, const orbx_epipolar_pair* pairs, int n_pairs,
                                       const float* scale_sigmas, int n_levels, int low_threshold,
                                       int check_orientation, orbx_match* matches, int* counts) {
+    ORBX_ENTER(h);
     if (!h || n_pairs < 0) return ORBX_BAD_ARG;
     if (n_pairs == 0) return ORBX_OK;
     if (!pairs || !counts || !scale_sigmas || n_levels <= 0) return ORBX_BAD_ARG;
@@ -2564,6 +2582,7 @@ orbx_status orbx_match_epipolar(orbx_matcher* h, const orbx_keypoint* keypoints,
                                 const uint32_t* ref_node_ids, const int32_t* ref_node_start,
                                 const int32_t* ref_node_items, int n_ref_nodes, int low_threshold,
                                 int check_orientation, orbx_match* matches, int* count) {
+    ORBX_ENTER(h);
     if (!h || !count) return ORBX_BAD_ARG;
     *count = 0;
     const orbx_epipolar_pair q{keypoints, n, descriptors, ref_keypoints, n_ref, ref_descriptors, has_point,
@@ -2579,6 +2598,7 @@ orbx_status orbx_fuse_search(orbx_matcher* h, const orbx_grid* g, const int32_t*
                              const uint8_t* point_descriptors, const float* scale_factors,
                              const float* inv_scale_sigmas, int n_levels, float radius_multiplier,
                              int32_t* best_index, int32_t* best_distance) {
+    ORBX_ENTER(h);
     if (!h || !g || n < 0 || n_points < 0) return ORBX_BAD_ARG;
     if (n_points == 0) return ORBX_OK;
     if (!best_index || !best_distance) return ORBX_BAD_ARG;
@@ -2649,6 +2669,7 @@ orbx_status orbx_fuse_search(orbx_matcher* h, const orbx_grid* g, const int32_t*
 
 orbx_status orbx_best_descriptor_batch(orbx_matcher* h, const uint8_t* descriptors, const int32_t* point_start,
                                        int n_points, int32_t* best_index) {
+    ORBX_ENTER(h);
     if (!h || !point_start || !best_index || n_points < 0) return ORBX_BAD_ARG;
     if (n_points == 0) return ORBX_OK;
     if (point_start[0] != 0) return ORBX_BAD_ARG;

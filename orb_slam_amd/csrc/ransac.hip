@@ -15,6 +15,7 @@ enum Stage { RT_NORMALIZE = 0, RT_SOLVE, RT_SCORE_F, RT_SCORE_H, RT_SELECT, RT_S
 }
 
 struct orbx_ransac {
+    CallGate gate;  // one call at a time (ORBX_ENTER)
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // the homography chain runs beside the fundamental chain (the reference uses two threads, Initializer.cpp:291-303)
@@ -145,6 +146,10 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};
+// One event per GPU marks the end of the last call that used that GPU's array: the next call, on whichever handle
+// and stream, makes its stream wait for it first, so calls that use the array run one after the other on the device
+// even when their streams would let them overlap.  Created with the address, at set-up: a call creates nothing.
+hipEvent_t g_scratch_done[kMaxDevices] = {};
 
 // Address of `scratch` on `device` (which must be the current device); looked up once per device.
 orbx_status resolve_scratch(int device, unsigned char** out) {
@@ -154,6 +159,9 @@ orbx_status resolve_scratch(int device, unsigned char** out) {
         unsigned char* ptr = nullptr;
         ORBX_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
         if (!ptr) return ORBX_DEVICE;
+        hipEvent_t ev = nullptr;
+        ORBX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g_scratch_done[device] = ev;
         g_scratch_ptr[device] = ptr;
     }
     *out = g_scratch_ptr[device];
@@ -228,6 +236,7 @@ void orbx_ransac_destroy(orbx_ransac* h) {
 }
 
 orbx_status orbx_ransac_set_stream(orbx_ransac* h, void* hip_stream) {
+    ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return ORBX_OK;
@@ -245,6 +254,7 @@ orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const fl
                                  const uint32_t* d_sets8, int iterations, int n_pairs, double sigma, float* d_F,
                                  float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h, float* d_scores,
                                  int32_t* d_best_iteration) {
+    ORBX_ENTER(h);
     if (!h || !d_points || !d_ref_points || !d_sets8 || !d_F || !d_H || !d_inliers_f || !d_inliers_h || !d_scores ||
         !d_best_iteration)
         return ORBX_BAD_ARG;
@@ -260,6 +270,7 @@ orbx_status orbx_ransac_fh_batch_static(orbx_ransac* h, const float* d_points, c
                                         const uint32_t* d_sets8, int iterations, int n_pairs, double sigma,
                                         float* d_F, float* d_H, uint8_t* d_inliers_f, uint8_t* d_inliers_h,
                                         float* d_scores, int32_t* d_best_iteration) {
+    ORBX_ENTER(h);
     if (!h || !d_points || !d_ref_points || !d_sets8 || !d_F || !d_H || !d_inliers_f || !d_inliers_h || !d_scores ||
         !d_best_iteration)
         return ORBX_BAD_ARG;
@@ -279,13 +290,21 @@ orbx_status orbx_ransac_fh_batch_static(orbx_ransac* h, const float* d_points, c
     const Workspace w{(float*)(base + kOffPn),   (float*)(base + kOffRn),    (float*)(base + kOffT),
                       (float*)(base + kOffFall), (float*)(base + kOffHall),  (float*)(base + kOffHiall),
                       (float*)(base + kOffSf),   (float*)(base + kOffSh),    (int32_t*)(base + kOffBad)};
-    return run_batch(h, w, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H, d_inliers_f,
-                     d_inliers_h, d_scores, d_best_iteration);
+    // queue behind the previous user of this GPU's array, and mark this call's end for the next one; the lock keeps
+    // wait -> launches -> record of two host threads from interleaving
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    hipEvent_t done = g_scratch_done[h->device];
+    ORBX_HIP(hipStreamWaitEvent(h->stream, done, 0));
+    const orbx_status st = run_batch(h, w, d_points, d_ref_points, n, d_sets8, iterations, n_pairs, sigma, d_F, d_H,
+                                     d_inliers_f, d_inliers_h, d_scores, d_best_iteration);
+    ORBX_HIP(hipEventRecord(done, h->stream));
+    return st;
 }
 
 orbx_status orbx_ransac_fh(orbx_ransac* h, const float* points, const float* ref_points, int n, const uint32_t* sets8,
                            int iterations, double sigma, float* F, float* H, uint8_t* inliers_f, uint8_t* inliers_h,
                            double* score_f, double* score_h, int32_t* best_iteration) {
+    ORBX_ENTER(h);
     if (!h || !points || !ref_points || !sets8 || !F || !H || !inliers_f || !inliers_h || !score_f || !score_h ||
         !best_iteration)
         return ORBX_BAD_ARG;
@@ -325,6 +344,7 @@ orbx_status orbx_ransac_fh(orbx_ransac* h, const float* points, const float* ref
 orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float* ref_points, int n,
                                const uint32_t* sets8, int iterations, double sigma, float* F_all, float* H_all,
                                float* Hinv_all, float* score_f, float* score_h) {
+    ORBX_ENTER(h);
     if (!h || !points || !ref_points || !sets8) return ORBX_BAD_ARG;
     if (n < 8 || iterations <= 0 || !(sigma > 0)) return ORBX_BAD_ARG;
     ORBX_TRY(check_sets(sets8, iterations, n));
@@ -354,6 +374,7 @@ orbx_status orbx_ransac_fh_all(orbx_ransac* h, const float* points, const float*
 // ---- the public solvers of geometry/utils.h for any number of correspondences ---------------------------------
 
 orbx_status orbx_normalize_points(orbx_ransac* h, const float* points, int n, float* normalized, float* T9) {
+    ORBX_ENTER(h);
     if (!h || !points || !normalized || !T9 || n <= 0) return ORBX_BAD_ARG;
     ORBX_HIP(hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -401,11 +422,13 @@ extern "C" {
 
 orbx_status orbx_fundamental_npt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems,
                                  float* F9) {
+    ORBX_ENTER(h);
     return solve_npt(h, points, ref_points, n, n_systems, 0, F9);
 }
 
 orbx_status orbx_homography_dlt(orbx_ransac* h, const float* points, const float* ref_points, int n, int n_systems,
                                 float* H9) {
+    ORBX_ENTER(h);
     return solve_npt(h, points, ref_points, n, n_systems, 1, H9);
 }
 
@@ -445,6 +468,7 @@ extern "C" {
 orbx_status orbx_recover_pose_batch(orbx_ransac* h, int n_pairs, const float* fundamental, const float* intrinsics,
                                     const double* points, const double* ref_points, const int32_t* pair_start,
                                     double* rotation, double* translation, int32_t* n_good) {
+    ORBX_ENTER(h);
     if (!h || n_pairs < 0) return ORBX_BAD_ARG;
     if (n_pairs == 0) return ORBX_OK;
     if (!fundamental || !intrinsics || !pair_start || !rotation || !translation || !n_good) return ORBX_BAD_ARG;
@@ -481,6 +505,7 @@ orbx_status orbx_recover_pose_batch(orbx_ransac* h, int n_pairs, const float* fu
 orbx_status orbx_triangulate_batch(orbx_ransac* h, int n_pairs, const float* intrinsics, const double* rotation,
                                    const double* translation, const double* points, const double* ref_points,
                                    const int32_t* pair_start, double* points_3d) {
+    ORBX_ENTER(h);
     if (!h || n_pairs < 0) return ORBX_BAD_ARG;
     if (n_pairs == 0) return ORBX_OK;
     if (!intrinsics || !rotation || !translation || !pair_start) return ORBX_BAD_ARG;

@@ -15,7 +15,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("octave", "<i4"), ("class_id", "<i4")])
 MATCH_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("img", "<i4"), ("distance", "<f4")])
 
-OK, BAD_ARG, CAPACITY, DEVICE, UNSUPPORTED = range(5)
+OK, BAD_ARG, CAPACITY, DEVICE, UNSUPPORTED, BUSY = range(6)
 
 # every symbol include/orbx.h declares
 SYMBOLS = [
@@ -72,7 +72,7 @@ class OrbxError(RuntimeError):
         self.status = status
         msg = lib().orbx_status_string(status).decode()
         detail = lib().orbx_last_error().decode()
-        super().__init__(f"{where}: {msg}" + (f" ({detail})" if detail and status in (DEVICE, CAPACITY) else ""))
+        super().__init__(f"{where}: {msg}" + (f" ({detail})" if detail and status in (DEVICE, CAPACITY, BUSY) else ""))
 
 
 _lib = None

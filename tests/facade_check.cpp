@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <orb_slam/geometry/orb_extractor.h>
 #include <orb_slam/geometry/orb_matcher.h>
+#include <orb_slam/geometry/utils.h>
 #include <orb_slam/initializer.h>
 
 #include <map>
@@ -94,6 +95,108 @@ struct MockKeyFrame {
     }
 };
 
+// 3x3 CV_32F products / transpose / inverse for the transcribed reference tests (the stand-in cv::Mat has no operators)
+static cv::Mat mul3(const cv::Mat& a, const cv::Mat& b) {
+    cv::Mat c(3, 3, CV_32F);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double t = 0;
+            for (int k = 0; k < 3; k++) t += (double)a.at<float>(i, k) * b.at<float>(k, j);
+            c.at<float>(i, j) = (float)t;
+        }
+    return c;
+}
+static cv::Mat transpose3(const cv::Mat& a) {
+    cv::Mat c(3, 3, CV_32F);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c.at<float>(j, i) = a.at<float>(i, j);
+    return c;
+}
+static cv::Mat inverse3(const cv::Mat& a) {
+    double m[9], d;
+    for (int i = 0; i < 9; i++) m[i] = a.at<float>(i / 3, i % 3);
+    d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    const double c[9] = {m[4] * m[8] - m[5] * m[7], m[2] * m[7] - m[1] * m[8], m[1] * m[5] - m[2] * m[4],
+                         m[5] * m[6] - m[3] * m[8], m[0] * m[8] - m[2] * m[6], m[2] * m[3] - m[0] * m[5],
+                         m[3] * m[7] - m[4] * m[6], m[1] * m[6] - m[0] * m[7], m[0] * m[4] - m[1] * m[3]};
+    cv::Mat out(3, 3, CV_32F);
+    for (int i = 0; i < 9; i++) out.at<float>(i / 3, i % 3) = (float)(c[i] / d);
+    return out;
+}
+static double distanceToGolden(cv::Mat m, const float* golden) {
+    if (std::fabs(m.at<float>(2, 2)) > 1e-8)
+        for (int i = 0; i < 9; i++) m.at<float>(i / 3, i % 3) *= (float)(1. / m.at<float>(2, 2));
+    double s = 0;
+    for (int i = 0; i < 9; i++) { const double d = (double)m.at<float>(i / 3, i % 3) - golden[i]; s += d * d; }
+    return std::sqrt(s);
+}
+static void printBits(const char* name, const cv::Mat& m) {
+    std::printf("%s=", name);
+    for (int i = 0; i < 9; i++) { uint32_t w; std::memcpy(&w, &m.at<float>(i / 3, i % 3), 4); std::printf("%08x%s", w, i < 8 ? "," : "\n"); }
+}
+
+// The bodies of the reference's src/tests/geometry/utils_tests.cpp:71-147 against the facade's geometry/utils.h.
+// `path` holds the reference's point tables and golden matrices: n, then n rows "px py rx ry", then F (9), then H (9).
+static void utilsTests(const char* path) {
+    std::ifstream f(path);
+    int n = 0;
+    f >> n;
+    std::vector<cv::Point2f> points(n), ref_points(n);
+    for (int i = 0; i < n; i++) f >> points[i].x >> points[i].y >> ref_points[i].x >> ref_points[i].y;
+    float cv_f_mat[9], cv_h_mat[9];
+    for (float& v : cv_f_mat) f >> v;
+    for (float& v : cv_h_mat) f >> v;
+    if (!f) { std::printf("utils_points unreadable\n"); return; }
+    {   // TestFundamentalMatrix
+        std::vector<cv::Point2f> points_norm, ref_points_norm;
+        cv::Mat T, ref_T, f_norm;
+        normalizePoints(points, points_norm, T);
+        normalizePoints(ref_points, ref_points_norm, ref_T);
+        computeFundamentalMat(f_norm, points_norm, ref_points_norm);
+        cv::Mat f_mat = mul3(mul3(transpose3(T), f_norm), ref_T);
+        std::printf("utils_F_err=%.9g n=%d\n", distanceToGolden(f_mat, cv_f_mat), n);
+        printBits("utils_F_norm", f_norm);
+        printBits("utils_T", T);
+    }
+    {   // TestHomographyMatrix
+        std::vector<cv::Point2f> points_norm, ref_points_norm;
+        cv::Mat T, ref_T, h_norm;
+        normalizePoints(points, points_norm, T);
+        normalizePoints(ref_points, ref_points_norm, ref_T);
+        computeHomographyMat(h_norm, points_norm, ref_points_norm);
+        cv::Mat h_mat = mul3(mul3(inverse3(T), h_norm), ref_T);
+        std::printf("utils_H_err=%.9g\n", distanceToGolden(h_mat, cv_h_mat));
+        printBits("utils_H_norm", h_norm);
+    }
+}
+
+// TestComputeThreeMaxima (utils_tests.cpp:123-147) plus the two helpers of namespace utils; host only
+static void utilsHostTests() {
+    const int hist_l = 30;
+    std::vector<int> hist[hist_l];
+    const int fill[8] = {10, 1, 20, 15, 9, 8, 7, 5};
+    for (int b = 0; b < 8; b++) hist[b].assign(fill[b], 1);
+    int m1, m2, m3;
+    computeThreeMaxima(hist, hist_l, m1, m2, m3);
+    std::printf("maxima=%d,%d,%d\n", m1, m2, m3);
+    cv::Mat d(4, 32, CV_8U);
+    for (int i = 0; i < 4 * 32; i++) d.data[i] = (unsigned char)(i * 37 + 11);
+    std::vector<cv::Mat> rows;
+    orb_slam::utils::matToVectorMat(d, rows);   // as Frame::computeBow calls it (src/frame.cpp:316)
+    bool shared = rows.size() == 4;
+    for (int r = 0; shared && r < 4; r++) shared = rows[r].rows == 1 && rows[r].cols == 32 && rows[r].data == d.data + 32 * r;
+    int bits = 0;
+    for (int i = 0; i < 32; i++) bits += __builtin_popcount(d.data[i] ^ d.data[32 + i]);
+    std::printf("rows_shared=%d distance_ok=%d\n", (int)shared, (int)(descriptorDistance(rows[0], rows[1]) == bits));
+    cv::Mat v(3, 1, CV_32F);
+    v.at<float>(0, 0) = 1.f; v.at<float>(1, 0) = 2.f; v.at<float>(2, 0) = 3.f;
+    cv::Mat k = orb_slam::utils::skew(v);
+    const float want[9] = {0, -3, 2, 3, 0, -1, -2, 1, 0};
+    bool ok = true;
+    for (int i = 0; i < 9; i++) ok = ok && k.at<float>(i / 3, i % 3) == want[i];
+    std::printf("skew_ok=%d\n", (int)ok);
+}
+
 int main(int argc, char** argv) {
     ros::NodeHandle nh;
     if (argc > 2) {
@@ -103,7 +206,9 @@ int main(int argc, char** argv) {
     int n_kp = -1;
     nh.getParam("orb_slam/orb_extractor/n_key_points", n_kp);
     std::printf("n_key_points=%d\n", n_kp);
+    utilsHostTests();
     if (argc < 2 || std::string(argv[1]) != "run") return 0;
+    if (argc > 3) utilsTests(argv[3]);
     ORBExtractor ex(nh, 640, 480);
     ORBMatcher mt(nh);
     cv::Mat img(480, 640, CV_8U);

@@ -104,8 +104,15 @@ int main(int argc, char** argv) {
     std::thread a(work, 0), b(work, 1);
     a.join();
     b.join();
+    // threads that start after those two have ended take over their handles: no new handle is made, however many
+    // short-lived threads pass through the shared objects
+    for (int round = 0; round < 3 && !shared_raw; round++) {
+        std::thread c(work, 0), e(work, 1);
+        c.join();
+        e.join();
+    }
     orbx_matcher_destroy(raw);
-    // one handle for the constructing thread and one per worker thread (plus the raw one)
+    // one handle for the constructing thread and one per concurrently running worker thread (plus the raw one)
     std::printf("matchers=%d extractors=%d\n", g_matchers - 1, g_extractors);
     return (shared_raw || (g_matchers - 1 == 3 && g_extractors == 3)) ? 0 : 1;
 }

@@ -12,7 +12,8 @@ EXE = os.path.join(ROOT, "tests", "facade_check")
 def _build():
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     cmd = ["g++", "-std=c++17", "-DORBX_NO_OPENCV", "-DORBX_NO_ROS", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "facade_check.cpp"), "-o", EXE, "-L" + os.path.join(ROOT, "orb_slam_amd"),
+           os.path.join(ROOT, "tests", "facade_check.cpp"), os.path.join(ROOT, "src", "geometry", "utils.cpp"),
+           "-o", EXE, "-L" + os.path.join(ROOT, "orb_slam_amd"),
            "-lorbx", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
            "-Wl,-rpath," + os.path.join(ROOT, "orb_slam_amd"), "-Wl,-rpath," + os.path.join(rocm, "lib")]
     subprocess.check_call(cmd)
@@ -22,6 +23,35 @@ def test_facade_compiles_and_reads_reference_yaml():
     _build()
     out = subprocess.check_output([EXE, "norun", os.path.join(ROOT, "tests", "golden", "cfg")], text=True)
     assert "n_key_points=1000" in out
+    # the host half of the reference's utils_tests (src/tests/geometry/utils_tests.cpp:123-147) and namespace utils
+    assert "maxima=2,3,0" in out and "rows_shared=1 distance_ok=1" in out and "skew_ok=1" in out
+
+
+def _cxx(args, **kw):
+    return subprocess.run(["g++", "-std=c++17", "-DORBX_NO_OPENCV", "-DORBX_NO_ROS", "-I" + os.path.join(ROOT, "include")]
+                          + args, capture_output=True, text=True, **kw)
+
+
+def test_reference_layout_translation_units_build_against_the_facade_header(tmp_path):
+    """The reference compiles src/geometry/utils.cpp (non-inline definitions of everything geometry/utils.h declares,
+    utils.cpp:18-264) and callers such as Frame::computeBow (src/frame.cpp:316) against the header.  A translation
+    unit of that layout must build against the facade header (no inline definition in it may collide), link on its
+    own, and the caller must also link against this repository's src/geometry/utils.cpp instead - but never both."""
+    tu = os.path.join(ROOT, "tests", "utils_tu_check.cpp")
+    own = str(tmp_path / "own")
+    r = _cxx([tu, "-DDEFINE_LIKE_THE_REFERENCE", "-o", own])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "rows=3 maxima=2,3,0" in subprocess.check_output([own], text=True)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    link = ["-L" + os.path.join(ROOT, "orb_slam_amd"), "-lorbx", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+            "-Wl,-rpath," + os.path.join(ROOT, "orb_slam_amd"), "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    ours = str(tmp_path / "ours")
+    r = _cxx([tu, os.path.join(ROOT, "src", "geometry", "utils.cpp"), "-o", ours] + link)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "rows=3 maxima=2,3,0" in subprocess.check_output([ours], text=True)
+    both = _cxx([tu, "-DDEFINE_LIKE_THE_REFERENCE", os.path.join(ROOT, "src", "geometry", "utils.cpp"), "-o",
+                 str(tmp_path / "both")] + link)
+    assert both.returncode != 0 and "multiple definition" in both.stderr
 
 
 def test_shared_facade_objects_are_thread_safe_under_tsan():
@@ -43,10 +73,31 @@ def test_shared_facade_objects_are_thread_safe_under_tsan():
 
 
 @pytest.mark.gpu
-def test_facade_runs_on_gpu():
+def test_facade_runs_on_gpu(tmp_path):
     if not os.path.exists(EXE):
         _build()
-    out = subprocess.check_output([EXE, "run", os.path.join(ROOT, "tests", "golden", "cfg")], text=True, timeout=120)
+    import numpy as np
+    from oracle import pyoracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", "utils_points.npz"))
+    table = tmp_path / "utils_points.txt"
+    with open(table, "w") as f:   # the reference's 79 pairs and golden matrices (utils_tests.cpp:15-121), as text
+        f.write(f"{len(g['points'])}\n")
+        for p, r in zip(g["points"], g["ref_points"]):
+            f.write(" ".join(repr(float(v)) for v in (p[0], p[1], r[0], r[1])) + "\n")
+        f.write(" ".join(repr(float(v)) for v in g["F_gold"].ravel()) + "\n")
+        f.write(" ".join(repr(float(v)) for v in g["H_gold"].ravel()) + "\n")
+    out = subprocess.check_output([EXE, "run", os.path.join(ROOT, "tests", "golden", "cfg"), str(table)], text=True,
+                                  timeout=120)
+    # src/tests/geometry/utils_tests.cpp:71-121 through geometry/utils.h -> src/geometry/utils.cpp -> the HIP solvers
+    assert f"n={len(g['points'])}" in out
+    assert float(out.split("utils_F_err=")[1].split()[0]) <= 1e-3     # EXPECT_NEAR(..., 1e-3), utils_tests.cpp:97
+    assert float(out.split("utils_H_err=")[1].split()[0]) <= 1.0      # EXPECT_NEAR(..., 1.0), utils_tests.cpp:120
+    pn, T = O.normalize_points(g["points"])
+    rn, _ = O.normalize_points(g["ref_points"])
+    bits = lambda m: ",".join(f"{w:08x}" for w in np.ascontiguousarray(m, np.float32).view(np.uint32).ravel())
+    assert f"utils_F_norm={bits(O.fundamental_8pt(pn, rn))}" in out
+    assert f"utils_H_norm={bits(O.homography_dlt(pn, rn))}" in out
+    assert f"utils_T={bits(T)}" in out
     assert "levels=8" in out and "H empty=0" in out
     kp = int(out.split("kp=")[1].split()[0])
     assert kp > 300 and f"desc={kp}" in out and f"matches=" in out

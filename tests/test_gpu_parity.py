@@ -114,9 +114,13 @@ def test_detect_edge_cases(oracle, ex1000):
     assert len(ex1000.detect(flat)) == 0 == len(oracle.detect(p, flat))
     tiny = synth_image(3, 70, 66)  # upper levels are smaller than twice the border: they yield nothing
     assert np.array_equal(ex1000.detect(tiny), oracle.detect(p, tiny).astype(orbx.KP_DTYPE))
+    # the size given at creation is a reservation: a larger image makes the buffers grow (cv::ORB takes any size)
+    big = synth_image(7, 1300, 900)
+    assert np.array_equal(ex1000.detect(big), oracle.detect(p, big).astype(orbx.KP_DTYPE))
+    assert np.array_equal(ex1000.detect(tiny), oracle.detect(p, tiny).astype(orbx.KP_DTYPE))
     with pytest.raises(orbx.OrbxError) as e:
-        ex1000.detect(np.zeros((2000, 2000), np.uint8))
-    assert e.value.status == orbx.CAPACITY
+        ex1000.detect(np.zeros((8, 16400), np.uint8))
+    assert e.value.status == orbx.UNSUPPORTED
     img = synth_image(5, 320, 240)
     with pytest.raises(orbx.OrbxError) as e:
         ex1000.detect(img, capacity=10)
@@ -134,6 +138,41 @@ def test_detect_edge_cases(oracle, ex1000):
     k2, d2 = ex.compute(dots, got)
     ok2, od2 = oracle.compute(p3, dots, want)
     assert np.array_equal(k2, ok2.astype(orbx.KP_DTYPE)) and np.array_equal(d2, od2)
+    ex.close()
+
+
+def test_one_handle_serves_one_call_at_a_time(oracle, test_images):
+    """A handle entered from a second thread while a call is running answers ORBX_BUSY and touches nothing: every call
+    that does go through returns the right keypoints, whichever thread made it."""
+    import threading
+    p = oracle.orb_params(nfeatures=1000)
+    want = oracle.detect(p, test_images[0]).astype(orbx.KP_DTYPE)
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480)
+    ex.detect(test_images[0])
+    stop = threading.Event()
+    seen = {"busy": 0, "ok": 0, "wrong": 0, "other": 0}
+
+    def second_caller():
+        while not stop.is_set():
+            try:
+                k = ex.detect(test_images[0])
+                seen["ok" if np.array_equal(k, want) else "wrong"] += 1
+            except orbx.OrbxError as e:
+                seen["busy" if e.status == orbx.BUSY else "other"] += 1
+
+    t = threading.Thread(target=second_caller)
+    t.start()
+    mine = {"busy": 0, "ok": 0, "wrong": 0, "other": 0}
+    for _ in range(300):
+        try:
+            k = ex.detect(test_images[0])
+            mine["ok" if np.array_equal(k, want) else "wrong"] += 1
+        except orbx.OrbxError as e:
+            mine["busy" if e.status == orbx.BUSY else "other"] += 1
+    stop.set()
+    t.join()
+    assert seen["wrong"] == 0 and mine["wrong"] == 0 and seen["other"] == 0 and mine["other"] == 0, (seen, mine)
+    assert seen["busy"] + mine["busy"] > 0 and seen["ok"] + mine["ok"] > 0, (seen, mine)
     ex.close()
 
 
@@ -162,13 +201,28 @@ def test_compute_reuses_the_pyramid_of_detect(oracle, test_images):
         buf[...] = test_images[1]
         k4, d4 = ex.compute(buf, want[1][0].astype(orbx.KP_DTYPE))
         assert np.array_equal(k4, want[1][1].astype(orbx.KP_DTYPE)) and np.array_equal(d4, want[1][2])
-        # an edit in place that touches a sampled row (row 0 is always sampled)
+        # a block edited in place
         k = ex.detect(buf)
         buf[0:40, 100:300] = 255 - buf[0:40, 100:300]
         ok = oracle.detect(p, buf)
         wk, wd = oracle.compute(p, buf, ok)
         k5, d5 = ex.compute(buf, ok.astype(orbx.KP_DTYPE))
         assert np.array_equal(d5, wd)
+        # an edit of a few pixels anywhere - single rows in the middle of the image, one pixel at a time: every pixel
+        # is part of the fingerprint, so the compute after it never describes the old pixels
+        stale_would_differ = 0
+        for row in (1, 7, 203, 331, 478):
+            k = ex.detect(buf)
+            kps = oracle.detect(p, buf)
+            _, old_d = oracle.compute(p, buf, kps)
+            near = kps[(np.abs(kps["y"] - row) < 6) & (kps["octave"] == 0)]
+            x = int(near["x"][0]) if len(near) else 320
+            buf[row, max(x - 3, 0):x + 4] = 255 - buf[row, max(x - 3, 0):x + 4]
+            wk, wd = oracle.compute(p, buf, kps)
+            stale_would_differ += not np.array_equal(wd, old_d)
+            k6, d6 = ex.compute(buf, kps.astype(orbx.KP_DTYPE))
+            assert np.array_equal(d6, wd), row
+        assert stale_would_differ >= 2   # the edits do change descriptors: a stale pyramid would have been caught
     ex.close()
 
 
@@ -531,6 +585,28 @@ def test_match_hamming_batch_ragged_pairs(oracle, matcher):
             oi, od = oracle.match_hamming(q[p, :nq], t[p, :nt])
             assert np.array_equal(idx[p, :nq], oi) and np.array_equal(dist[p, :nq], od), (p, nq, nt)
         assert (idx[p, nq:] == -7).all()                              # rows past a pair's count are not written
+    # counts ABOVE the capacities the call names (they are device data the call cannot look at): every count is
+    # read as min(count, capacity), so no result lands in a neighbouring pair's rows or past the buffers
+    over_q = torch.tensor([cap_q + 500 if i % 2 else a for i, (a, _) in enumerate(sizes)], dtype=torch.int32, device="cuda")
+    over_t = torch.tensor([cap_t + 77 if i % 3 == 0 else b for i, (_, b) in enumerate(sizes)], dtype=torch.int32, device="cuda")
+    d_idx.fill_(-7)
+    d_dist.fill_(-7)
+    guard = torch.full((4096,), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    matcher.match_hamming_batch(d_q.data_ptr(), over_q.data_ptr(), cap_q * 32, d_t.data_ptr(), over_t.data_ptr(),
+                                cap_t * 32, P, cap_q, cap_t, d_idx.data_ptr(), d_dist.data_ptr(), cap_q)
+    torch.cuda.synchronize()
+    idx2, dist2 = d_idx.cpu().numpy(), d_dist.cpu().numpy()
+    for p_, (nq, nt) in enumerate(sizes):
+        nq2 = cap_q if p_ % 2 else nq
+        nt2 = cap_t if p_ % 3 == 0 else nt
+        if nt2 == 0:
+            assert (idx2[p_, :nq2] == -1).all()
+        else:
+            oi, od = oracle.match_hamming(q[p_, :nq2], t[p_, :nt2])
+            assert np.array_equal(idx2[p_, :nq2], oi) and np.array_equal(dist2[p_, :nq2], od), (p_, nq2, nt2)
+        assert (idx2[p_, nq2:] == -7).all()
+    assert (guard.cpu().numpy() == -7).all()
     # every query set against every train set in one call (pair q * n_train_sets + t), sets 3..8 against sets 2..9
     QS, TS = list(range(3, 9)), list(range(2, 10))
     c_idx = torch.full((len(QS) * len(TS), cap_q), -7, dtype=torch.int32, device="cuda")

@@ -35,10 +35,12 @@ def _run(torch, rs, fn, pts, ref, sets, sigma):
     d_sc = torch.full((P, 2), -7.0, dtype=torch.float32, device="cuda")
     d_best = torch.full((P, 2), 77, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
     fn(d_pts.data_ptr(), d_ref.data_ptr(), n, d_sets.data_ptr(), it, P, sigma, d_F.data_ptr(), d_H.data_ptr(),
        d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_best.data_ptr())
     torch.cuda.synchronize()
-    return [t.cpu().numpy() for t in (d_F, d_H, d_if, d_ih, d_sc, d_best)]
+    free_after = torch.cuda.mem_get_info()[0]
+    return [t.cpu().numpy() for t in (d_F, d_H, d_if, d_ih, d_sc, d_best)], free_before - free_after
 
 
 def _case(rng, P, n, it, bad_pair=None):
@@ -61,8 +63,9 @@ def test_static_workspace_equals_allocating_entry_point():
     # takes the pair-by-pair scoring path
     for P, n, it, bad in ((31, 2000, 1000, 4), (7, 300, 200, None), (3, 64, 20, None)):
         pts, ref, sets = _case(rng, P, n, it, bad)
-        want = _run(torch, rs, rs.fh_batch, pts, ref, sets, 1.0)
-        got = _run(torch, rs, rs.fh_batch_static, pts, ref, sets, 1.0)
+        want, _ = _run(torch, rs, rs.fh_batch, pts, ref, sets, 1.0)
+        got, taken = _run(torch, rs, rs.fh_batch_static, pts, ref, sets, 1.0)
+        assert taken == 0, f"the call took {taken} bytes of device memory"   # hipMemGetInfo: free bytes unchanged
         for name, a, b in zip(("F", "H", "inliers_f", "inliers_h", "scores", "best"), got, want):
             assert a.tobytes() == b.tobytes(), (P, n, it, name)
         best = got[5]
@@ -76,4 +79,28 @@ def test_static_workspace_equals_allocating_entry_point():
         with pytest.raises(orbx.OrbxError) as e:
             rs.fh_batch_static(1, 1, n, 1, it, P, 1.0, 1, 1, 1, 1, 1, 1)
         assert e.value.status == orbx.CAPACITY and "exceed the fixed workspace" in str(e.value)
+    # two handles on streams of their own share the GPU's one array: the library makes the second call wait for the
+    # first on the device, so both come back right (alone they would overwrite each other's hypotheses)
+    rs2 = orbx.Ransac()
+    a, b = _case(rng, 24, 1200, 900, None), _case(rng, 20, 900, 700, None)
+    want_a, _ = _run(torch, rs, rs.fh_batch, *a, 1.0)
+    want_b, _ = _run(torch, rs2, rs2.fh_batch, *b, 1.0)
+    for _ in range(3):
+        bufs = []
+        for r, (pts, ref, sets) in ((rs, a), (rs2, b)):
+            P, n, it = pts.shape[0], pts.shape[1], sets.shape[1]
+            d = [torch.from_numpy(pts).cuda(), torch.from_numpy(ref).cuda(),
+                 torch.from_numpy(sets.astype(np.int64)).to(torch.int32).cuda(),
+                 torch.zeros((P, 9), dtype=torch.float32, device="cuda"), torch.zeros((P, 9), dtype=torch.float32, device="cuda"),
+                 torch.zeros((P, n), dtype=torch.uint8, device="cuda"), torch.zeros((P, n), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((P, 2), dtype=torch.float32, device="cuda"), torch.zeros((P, 2), dtype=torch.int32, device="cuda")]
+            bufs.append((r, n, it, P, d))
+        torch.cuda.synchronize()
+        for r, n, it, P, d in bufs:   # queued back to back, no host wait in between
+            r.fh_batch_static(d[0].data_ptr(), d[1].data_ptr(), n, d[2].data_ptr(), it, P, 1.0, *[t.data_ptr() for t in d[3:]])
+        torch.cuda.synchronize()
+        for (r, n, it, P, d), want in zip(bufs, (want_a, want_b)):
+            for name, t, w in zip(("F", "H", "inliers_f", "inliers_h", "scores", "best"), d[3:], want):
+                assert t.cpu().numpy().tobytes() == w.tobytes(), name
+    rs2.close()
     rs.close()
