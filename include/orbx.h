@@ -372,7 +372,7 @@ orbx_status orbx_ransac_fh_batch(orbx_ransac* h, const float* d_points, const fl
 /* orbx_ransac_fh_batch for callers that cannot allocate device memory while they run (tight serving loops,
    harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit; the
    intermediate arrays (normalised points, every hypothesis and its score) live in a fixed device array of about
-   5.9 MB that each GPU the library runs on holds until the process ends, and the call makes no hipMalloc / hipFree
+   10.1 MB that each GPU the library runs on holds until the process ends, and the call makes no hipMalloc / hipFree
    (nor any other allocating call: its events exist since orbx_ransac_create).  Limits per call: n_pairs <= 1024,
    n_pairs * iterations <= 32768, n_pairs * n <= 131072; beyond them ORBX_CAPACITY is returned (orbx_last_error()
    names the limits) and nothing runs.  Every call on a GPU shares that GPU's array, whichever handle it goes
@@ -429,6 +429,12 @@ orbx_status orbx_triangulate_batch(orbx_ransac* h, int n_pairs, const float* int
 /* The reference's set generator (Initializer.cpp:261-277: cumulative std::shuffle, first 8) with a caller-chosen
    seed per iteration (seed0 + it) in place of std::random_device.  Host arithmetic. */
 orbx_status orbx_ransac_make_sets(int n, int iterations, uint32_t seed0, uint32_t* sets8);
+
+/* No counterpart in the reference: scheduling of the RANSAC entry points.  Enabled (the default), the homography
+   chain (solve, score) runs on a second stream of the handle beside the fundamental chain, as the reference's two
+   threads do (src/Initializer.cpp:291-303); disabled, the kernels run one after the other on the handle's stream
+   (each then has the chip to itself: what a profile of single kernels wants).  Results are identical. */
+orbx_status orbx_ransac_set_fork(orbx_ransac* h, int enabled);
 
 /* Per-kernel launch durations (ms) of the last batch call: normalize, solve_f, score_f, score_h, select, solve_h
    (the homography kernels run on a side stream beside the fundamental ones, so the durations overlap). */

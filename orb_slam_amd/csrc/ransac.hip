@@ -21,11 +21,13 @@ struct orbx_ransac {
     // the homography chain runs beside the fundamental chain (the reference uses two threads, Initializer.cpp:291-303)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_h = true;                       // homography chain on the side stream (orbx_ransac_set_fork)
     unsigned char* static_scratch = nullptr;  // this GPU's copy of the file-scope workspace
     DevBuf<float> d_pts, d_ref, d_pn, d_rn, d_T, d_Fall, d_Hall, d_Hiall, d_sf, d_sh, d_F, d_H, d_scores;
     DevBuf<uint32_t> d_sets;
     DevBuf<uint8_t> d_inlf, d_inlh;
     DevBuf<int32_t> d_best, d_bad;
+    DevBuf<double> d_pd;
     // pose recovery
     DevBuf<double> d_ppts, d_pref, d_cand, d_norm, d_R, d_t, d_xyz;
     DevBuf<float> d_K, d_Fp;
@@ -42,6 +44,7 @@ namespace {
 struct Workspace {
     float *pn, *rn, *T, *Fall, *Hall, *Hiall, *sf, *sh;
     int32_t* bad;
+    double* pd;  // [pairs][n][4]: the correspondences widened to double for the fundamental scorer
 };
 
 // The handle's own (growing) buffers as the workspace of a batch.
@@ -56,8 +59,9 @@ orbx_status handle_workspace(orbx_ransac* h, int n, int iterations, int pairs, W
     ORBX_TRY(h->d_sf.ensure(hyp));
     ORBX_TRY(h->d_sh.ensure(hyp));
     ORBX_TRY(h->d_bad.ensure(pairs));
+    ORBX_TRY(h->d_pd.ensure(pn * 2));
     *w = Workspace{h->d_pn.p, h->d_rn.p, h->d_T.p, h->d_Fall.p, h->d_Hall.p, h->d_Hiall.p, h->d_sf.p, h->d_sh.p,
-                   h->d_bad.p};
+                   h->d_bad.p, h->d_pd.p};
     return ORBX_OK;
 }
 
@@ -69,18 +73,22 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
     StageTimer& T = h->timer;
     T.clear();
     T.begin(RT_NORMALIZE, s);
-    hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, w.pn, w.rn, w.T);
+    hipLaunchKernelGGL(k_normalize, dim3(pairs, 2), dim3(64), 0, s, d_points, d_ref, n, w.pn, w.rn, w.T, w.pd);
     T.end(RT_NORMALIZE, s);
+    // hypotheses are numbered through across pairs, 64 per scoring workgroup; with very few iterations per pair a
+    // workgroup would span many pairs - the scorers then simply run pair by pair
+    const bool flat = iterations >= kScoreMinIterations;
     const int hyp_blocks64 = (int)(((long long)pairs * iterations + 63) / 64);
-    // a 256-hypothesis workgroup spans at most kScorePairs pairs when iterations >= 86; below that, one launch
-    // per group of pairs would be needed - the scorers then simply run pair by pair
-    const bool flat = iterations >= 86;
-    const int score_blocks = flat ? (int)(((long long)pairs * iterations + 255) / 256) : div_up(iterations, 256);
-    // F chain on the handle's stream, H chain on the side stream: neither fills the chip alone (3200 wavefronts for
-    // 1024 SIMDs at 1024 pairs x 200 iterations), together they leave fewer idle slots
-    hipStream_t sh = h->side_stream;
-    ORBX_HIP(hipEventRecord(h->ev_fork, s));
-    ORBX_HIP(hipStreamWaitEvent(sh, h->ev_fork, 0));
+    const int score_blocks = flat ? hyp_blocks64 : div_up(iterations, 64);
+    // F chain on the handle's stream, H chain on the side stream (the reference uses two threads,
+    // Initializer.cpp:291-303): the solvers hold a whole system in registers and run two wavefronts per SIMD, so
+    // neither chain fills the chip alone.  (Cutting a large batch into parts of pairs, solve and score alternating
+    // on each stream, was measured slower: 2.76 ms whole, 2.78 in two parts, 3.08 in four.)
+    hipStream_t sh = h->fork_h ? h->side_stream : s;
+    if (h->fork_h) {
+        ORBX_HIP(hipEventRecord(h->ev_fork, s));
+        ORBX_HIP(hipStreamWaitEvent(sh, h->ev_fork, 0));
+    }
     T.begin(RT_SOLVE, s);
     hipLaunchKernelGGL(k_solve_f, dim3(hyp_blocks64), dim3(64), 0, s, w.pn, w.rn, n, w.T, d_sets8,
                        iterations, pairs, w.Fall, w.bad);
@@ -92,13 +100,12 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
     T.begin(RT_SCORE_H, sh);
     T.begin(RT_SCORE_F, s);
     if (flat)
-        hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points, d_ref, n, w.Fall, iterations,
-                           pairs, sigma, w.sf);
+        hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, w.pd, n, w.Fall, iterations, pairs, sigma,
+                           w.sf);
     else
         for (int p = 0; p < pairs; p++)
-            hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, d_points + (size_t)p * n * 2,
-                               d_ref + (size_t)p * n * 2, n, w.Fall + (size_t)p * iterations * 9, iterations, 1,
-                               sigma, w.sf + (size_t)p * iterations);
+            hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, w.pd + (size_t)p * n * 4, n,
+                               w.Fall + (size_t)p * iterations * 9, iterations, 1, sigma, w.sf + (size_t)p * iterations);
     T.end(RT_SCORE_F, s);
     if (flat)
         hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points, d_ref, n, w.Hall,
@@ -110,8 +117,10 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
                                w.Hiall + (size_t)p * iterations * 9, iterations, 1, sigma,
                                w.sh + (size_t)p * iterations);
     T.end(RT_SCORE_H, sh);
-    ORBX_HIP(hipEventRecord(h->ev_join, sh));
-    ORBX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    if (h->fork_h) {
+        ORBX_HIP(hipEventRecord(h->ev_join, sh));
+        ORBX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    }
     T.begin(RT_SELECT, s);
     hipLaunchKernelGGL(k_select, dim3(pairs, 2), dim3(256), 0, s, d_points, d_ref, n, w.Fall, w.Hall,
                        w.Hiall, w.sf, w.sh, w.bad, iterations, sigma, d_F, d_H, d_inl_f, d_inl_h,
@@ -136,7 +145,8 @@ constexpr size_t kOffHiall = kOffHall + align256(kStaticMaxHyp * 9 * sizeof(floa
 constexpr size_t kOffSf = kOffHiall + align256(kStaticMaxHyp * 9 * sizeof(float));
 constexpr size_t kOffSh = kOffSf + align256(kStaticMaxHyp * sizeof(float));
 constexpr size_t kOffBad = kOffSh + align256(kStaticMaxHyp * sizeof(float));
-constexpr size_t kScratchBytes = kOffBad + align256(kStaticMaxPairs * sizeof(int32_t));  // about 5.9 MB
+constexpr size_t kOffPd = kOffBad + align256(kStaticMaxPairs * sizeof(int32_t));
+constexpr size_t kScratchBytes = kOffPd + align256(kStaticMaxPoints * 4 * sizeof(double));  // about 10.1 MB
 
 // Every GPU the library runs on holds its own copy of this array until the process ends.  In host code the name
 // is only a handle for hipGetSymbolAddress: the device address it yields (one per GPU) is what kernels and
@@ -223,7 +233,7 @@ void orbx_ransac_destroy(orbx_ransac* h) {
     h->d_pts.release(); h->d_ref.release(); h->d_pn.release(); h->d_rn.release(); h->d_T.release();
     h->d_Fall.release(); h->d_Hall.release(); h->d_Hiall.release(); h->d_sf.release(); h->d_sh.release();
     h->d_F.release(); h->d_H.release(); h->d_scores.release(); h->d_sets.release(); h->d_inlf.release();
-    h->d_inlh.release(); h->d_best.release(); h->d_bad.release();
+    h->d_inlh.release(); h->d_best.release(); h->d_bad.release(); h->d_pd.release();
     h->d_ppts.release(); h->d_pref.release(); h->d_cand.release(); h->d_norm.release(); h->d_R.release();
     h->d_t.release(); h->d_xyz.release(); h->d_K.release(); h->d_Fp.release(); h->d_pstart.release();
     h->d_good.release(); h->d_count.release();
@@ -239,6 +249,12 @@ orbx_status orbx_ransac_set_stream(orbx_ransac* h, void* hip_stream) {
     ORBX_ENTER(h);
     if (!h) return ORBX_BAD_ARG;
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return ORBX_OK;
+}
+
+orbx_status orbx_ransac_set_fork(orbx_ransac* h, int enabled) {
+    ORBX_ENTER(h);
+    h->fork_h = enabled != 0;
     return ORBX_OK;
 }
 
@@ -289,7 +305,8 @@ orbx_status orbx_ransac_fh_batch_static(orbx_ransac* h, const float* d_points, c
     unsigned char* base = h->static_scratch;
     const Workspace w{(float*)(base + kOffPn),   (float*)(base + kOffRn),    (float*)(base + kOffT),
                       (float*)(base + kOffFall), (float*)(base + kOffHall),  (float*)(base + kOffHiall),
-                      (float*)(base + kOffSf),   (float*)(base + kOffSh),    (int32_t*)(base + kOffBad)};
+                      (float*)(base + kOffSf),   (float*)(base + kOffSh),    (int32_t*)(base + kOffBad),
+                      (double*)(base + kOffPd)};
     // queue behind the previous user of this GPU's array, and mark this call's end for the next one; the lock keeps
     // wait -> launches -> record of two host threads from interleaving
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -384,7 +401,7 @@ orbx_status orbx_normalize_points(orbx_ransac* h, const float* points, int n, fl
     ORBX_HIP(hipMemcpyAsync(h->d_pts.p, points, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
     // one point set: side 0 of a single pair (the reference-side arguments are never touched)
     hipLaunchKernelGGL(k_normalize, dim3(1, 1), dim3(64), 0, s, h->d_pts.p, h->d_pts.p, n, h->d_pn.p, h->d_pn.p,
-                       h->d_T.p);
+                       h->d_T.p, (double*)nullptr);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipMemcpyAsync(normalized, h->d_pn.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
     ORBX_HIP(hipMemcpyAsync(T9, h->d_T.p, sizeof(float) * 9, hipMemcpyDeviceToHost, s));

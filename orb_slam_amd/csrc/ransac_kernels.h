@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace orbx {
 
 // IEEE double hypot with the evaluation order of glibc 2.35's generic (non-FMA) __hypot, which is what
@@ -50,12 +52,22 @@ __device__ __forceinline__ double hypot_f64(double x, double y) {
     return hypot_kernel(ax, ay);
 }
 
+// x * y + z for FLOAT-valued x and y, in double.  The product of two floats has at most 48 significant bits and an
+// exponent far inside the double range: it is exact, so the separate multiply and add of the scalar code round once,
+// in the addition, and the fused form rounds the same sum once - the same bits, one instruction instead of two.
+// (Only for products of two float-valued operands; anywhere else fusing would change results.)
+__device__ __forceinline__ double fma_exact_product(float x, float y, double z) {
+    return __builtin_fma((double)x, (double)y, z);
+}
+
 // cv::JacobiSVDImpl_<float> (OpenCV 3.4 core/lapack.cpp): one-sided Jacobi on the N rows (length M) of At, with
 // the rotations accumulated in Vt (N x N) when WANT_V.  Every loop over rows and columns is unrolled and every
 // index is a compile-time constant, so At, Vt and W live in registers (one hypothesis per lane, no scratch memory);
 // the operations and their order are those of the scalar loops.  On return W holds the squared row norms as the
 // sweeps left them (OpenCV recomputes them next: see svd_finish).
-template <int M, int N, bool WANT_V>
+// FUSE selects fma_exact_product for the dot products and row norms (same bits either way; whichever form leaves
+// the caller's register allocation better off is used).
+template <int M, int N, bool WANT_V, bool FUSE = true>
 __device__ __forceinline__ void jacobi_sweeps(float (&At)[N * M], float (&Vt)[WANT_V ? N * N : 1], double (&W)[N]) {
     const float eps = 1.1920928955078125e-7f * 2;  // FLT_EPSILON * 2
     const int max_iter = M > 30 ? M : 30;
@@ -65,7 +77,7 @@ __device__ __forceinline__ void jacobi_sweeps(float (&At)[N * M], float (&Vt)[WA
 #pragma unroll
         for (int k = 0; k < M; k++) {
             const float t = At[i * M + k];
-            sd += (double)t * t;
+            sd = FUSE ? fma_exact_product(t, t, sd) : sd + (double)t * t;
         }
         W[i] = sd;
         if (WANT_V) {
@@ -81,7 +93,8 @@ __device__ __forceinline__ void jacobi_sweeps(float (&At)[N * M], float (&Vt)[WA
             for (int j = i + 1; j < N; j++) {
                 double a = W[i], p = 0, b = W[j];
 #pragma unroll
-                for (int k = 0; k < M; k++) p += (double)At[i * M + k] * At[j * M + k];
+                for (int k = 0; k < M; k++)
+                    p = FUSE ? fma_exact_product(At[i * M + k], At[j * M + k], p) : p + (double)At[i * M + k] * At[j * M + k];
                 if (fabs(p) <= eps * sqrt((double)a * b)) continue;
                 p *= 2;
                 const double beta = a - b, gamma = hypot_f64((double)p, beta);
@@ -101,8 +114,8 @@ __device__ __forceinline__ void jacobi_sweeps(float (&At)[N * M], float (&Vt)[WA
                     const float t1 = -s * At[i * M + k] + c * At[j * M + k];
                     At[i * M + k] = t0;
                     At[j * M + k] = t1;
-                    a += (double)t0 * t0;
-                    b += (double)t1 * t1;
+                    a = FUSE ? fma_exact_product(t0, t0, a) : a + (double)t0 * t0;
+                    b = FUSE ? fma_exact_product(t1, t1, b) : b + (double)t1 * t1;
                 }
                 W[i] = a;
                 W[j] = b;
@@ -134,7 +147,7 @@ __device__ __forceinline__ void svd_finish(float (&At)[N * M], float (&Vt)[WANT_
 #pragma unroll
         for (int k = 0; k < M; k++) {
             const float t = At[i * M + k];
-            sd += (double)t * t;
+            sd = fma_exact_product(t, t, sd);
         }
         W[i] = sqrt(sd);
         perm[i] = i;
@@ -256,9 +269,12 @@ __device__ __forceinline__ void scale33(float* M, double alpha) {
 // geometry::normalizePoints (reference src/geometry/utils.cpp:18-52) for one point set per wavefront.
 // The float coordinate sums and the double sum of distances are accumulated by lane 0 in index order; the
 // per-point arithmetic runs on all lanes.  Output: normalised points and T (row-major 3x3).
+// With pd non-null the un-normalised coordinates are also stored widened to double, one (u1, v1, u2, v2) record per
+// correspondence (reference point, then point): what the fundamental scorer reads, so that the widening happens once
+// per correspondence and not once per hypothesis.
 __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts, const float* __restrict__ ref, int n,
                                                   float* __restrict__ pts_n, float* __restrict__ ref_n,
-                                                  float* __restrict__ T_all) {
+                                                  float* __restrict__ T_all, double* __restrict__ pd) {
     __shared__ double s_norm[1024];
     __shared__ double s_bcast[3];
     const int pair = blockIdx.x, side = blockIdx.y, lane = threadIdx.x;
@@ -289,6 +305,10 @@ __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts,
     }
     __syncthreads();
     const double mean_x = s_bcast[0], mean_y = s_bcast[1];
+    if (pd) {
+        double2* rec = (double2*)(pd + (size_t)pair * n * 4) + (side == 0 ? 1 : 0);  // side 0 = the points: (u2, v2)
+        for (int i = lane; i < n; i += 64) rec[2 * i] = make_double2((double)in[2 * i], (double)in[2 * i + 1]);
+    }
     double scale = 0.0;
     for (int base = 0; base < n; base += 1024) {
         const int cnt = min(1024, n - base);
@@ -325,7 +345,10 @@ __global__ __launch_bounds__(64) void k_normalize(const float* __restrict__ pts,
 // K11F: one hypothesis per lane.  geometry::computeFundamentalMat (utils.cpp:61-103) on the 8 normalised
 // correspondences of the set, then the de-normalisation and scaling of Initializer::findFundamentalMat
 // (Initializer.cpp:336-345).
-__global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
+#ifndef ORBX_SOLVE_F_WAVES
+#define ORBX_SOLVE_F_WAVES 2
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ORBX_SOLVE_F_WAVES, ORBX_SOLVE_F_WAVES))) void k_solve_f(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
                                                 const float* __restrict__ T_all, const uint32_t* __restrict__ sets8,
                                                 int iterations, int pairs, float* __restrict__ F_all,
                                                 int32_t* __restrict__ bad_sets) {
@@ -395,6 +418,8 @@ __global__ __launch_bounds__(64) void k_solve_f(const float* __restrict__ pts_n,
     for (int k = 0; k < 9; k++) F_all[o + k] = F[k];
 }
 
+constexpr bool kFuseSolveH = false;  // fused, the 9 x 16 system no longer fits 256 registers (it spills)
+
 // K11H: one hypothesis per lane.  geometry::computeHomographyMat (utils.cpp:112-154), then the de-normalisation,
 // inverse and scaling of Initializer::findHomographyMat (Initializer.cpp:476-486).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_solve_h(const float* __restrict__ pts_n, const float* __restrict__ ref_n, int n,
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         At[3 * 16 + c1] = 0.0f; At[4 * 16 + c1] = 0.0f; At[5 * 16 + c1] = 0.0f;
         At[6 * 16 + c1] = -u2 * u1; At[7 * 16 + c1] = -u2 * v1; At[8 * 16 + c1] = -u2;
     }
-    jacobi_sweeps<16, 9, true>(At, Vt, W);
+    jacobi_sweeps<16, 9, true, kFuseSolveH>(At, Vt, W);
     svd_finish<16, 9, true, false>(At, Vt, W, perm);
     // vt.row(8): the row the sort leaves last
     float Hn[9];
@@ -690,82 +715,156 @@ __global__ __launch_bounds__(64) void k_solve_npt(const float* __restrict__ pts,
     for (int k = 0; k < 9; k++) out[k] = Fn[k];
 }
 
-constexpr int kScoreChunk = 512;    // correspondences per pair staged in LDS at a time
-constexpr int kScorePairs = 4;      // pairs a 256-hypothesis workgroup may span (iterations >= 86)
+// ---- scoring ---------------------------------------------------------------------------------------------------
+// Initializer::checkFundamentalScore / checkHomographyScore (Initializer.cpp:369-444, 501-585) add one term per
+// correspondence and side to a running score, in index order; that chain of additions is the only part whose order
+// matters.  The terms themselves (two point-to-line or transfer distances, two IEEE divides: nearly all of the
+// arithmetic) are independent.  A workgroup scores 64 hypotheses (lane = hypothesis).  Its four wavefronts each
+// evaluate the terms of a quarter of a chunk of kScoreChunk correspondences for those 64 hypotheses and park them in
+// LDS; after one barrier a single wavefront - they take turns, the running scores travel through LDS - adds the
+// chunk's terms in index order while the other three already work on the next chunk (two term buffers).  Four times
+// as many wavefronts as hypotheses / 64, so the SIMDs are evenly loaded whatever pairs x iterations is.
+// A term that the reference skips (chi-square above the threshold) is parked as +0.0: the running score is never
+// negative zero, so adding it changes nothing; a NaN distance is not "above" and is added, as in the reference.
+// Hypotheses of all pairs are numbered through (hyp = pair * iterations + iteration): with iterations >= 63 the 64
+// hypotheses of a workgroup lie in at most two pairs.  The correspondences are the same for all lanes of a pair: a
+// wavefront whose lanes share one pair reads them through the scalar path.
+#ifndef ORBX_SCORE_CHUNK_H
+#define ORBX_SCORE_CHUNK_H 16
+#endif
+#ifndef ORBX_SCORE_CHUNK_F
+#define ORBX_SCORE_CHUNK_F 16
+#endif
+constexpr int kScoreChunk = ORBX_SCORE_CHUNK_H;   // correspondences per chunk of the homography scorer (a quarter per wavefront)
+constexpr int kScoreChunkF = ORBX_SCORE_CHUNK_F;  // the same for the fundamental scorer (its terms are doubles: twice the LDS)
+constexpr int kScoreMinIterations = 63;
 
-// Hypotheses of all pairs are numbered through (hyp = pair * iterations + iteration) and a workgroup takes 256
-// consecutive ones, so wavefronts stay full when `iterations` is no multiple of 64; it stages the correspondences
-// of the (at most kScorePairs) pairs it spans, and every lane walks its own pair's points in index order.
-struct ScoreSpan {
-    int pair, it, slot, p_first, n_pairs;
+struct ScoreLane {
+    int pair, it;
     bool live;
 };
 
-__device__ __forceinline__ ScoreSpan score_span(int iterations, int pairs) {
-    ScoreSpan sp;
-    const long long h0 = (long long)blockIdx.x * 256, total = (long long)pairs * iterations;
-    const long long hyp = h0 + threadIdx.x;
-    sp.live = hyp < total;
-    const long long hc = sp.live ? hyp : total - 1;
-    sp.pair = (int)(hc / iterations);
-    sp.it = (int)(hc - (long long)sp.pair * iterations);
-    sp.p_first = (int)(h0 / iterations);
-    const int p_last = (int)(min(h0 + 255, total - 1) / iterations);
-    sp.n_pairs = p_last - sp.p_first + 1;
-    sp.slot = sp.pair - sp.p_first;
-    return sp;
+__device__ __forceinline__ ScoreLane score_lane(int iterations, int pairs) {
+    ScoreLane sl;
+    const long long total = (long long)pairs * iterations;
+    const long long hyp = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    sl.live = hyp < total;
+    const long long hc = sl.live ? hyp : total - 1;
+    sl.pair = (int)(hc / iterations);
+    sl.it = (int)(hc - (long long)sl.pair * iterations);
+    return sl;
 }
 
-__device__ __forceinline__ void score_stage(float4 (*s_pt)[kScoreChunk], const ScoreSpan& sp, const float* pts,
-                                            const float* ref, int n, int base, int cnt) {
-    for (int i = threadIdx.x; i < cnt * sp.n_pairs; i += 256) {
-        const int q = i / cnt, j = i - q * cnt;
-        const float2* p2 = (const float2*)(pts + (size_t)(sp.p_first + q) * n * 2);
-        const float2* r2 = (const float2*)(ref + (size_t)(sp.p_first + q) * n * 2);
-        const float2 a = r2[base + j], b = p2[base + j];
-        s_pt[q][j] = make_float4(a.x, a.y, b.x, b.y);
+// The correspondences of a lane's pair.  UNIFORM: every lane of the wavefront has the same pair, whose index sits
+// in a scalar register - the compiler then sees addresses that do not depend on the lane and reads the points through
+// the scalar cache.  Otherwise each lane reads through its own pair's pointers.
+template <bool UNIFORM>
+struct PairPoints {
+    const float2* p2;
+    const float2* r2;
+    __device__ __forceinline__ PairPoints(const float* pts, const float* ref, int n, int pair) {
+        const int use = UNIFORM ? __builtin_amdgcn_readfirstlane(pair) : pair;
+        p2 = (const float2*)(pts + (size_t)use * n * 2);
+        r2 = (const float2*)(ref + (size_t)use * n * 2);
     }
-}
+};
 
-// K12F: Initializer::checkFundamentalScore (Initializer.cpp:369-444) for one hypothesis per lane; fp64.
-__global__ __launch_bounds__(256) void k_score_f(const float* __restrict__ pts, const float* __restrict__ ref, int n,
+// K12F: Initializer::checkFundamentalScore (Initializer.cpp:369-444); fp64.  pd: the correspondences widened to
+// double by k_normalize, (u1, v1, u2, v2) per record.  f11 * u1 and its like are products of two float-valued
+// doubles: exact, so `f11 * u1 + f12 * v1` is evaluated as one fused operation on the exact first product (see
+// fma_exact_product); the remaining operations involve full doubles and stay un-fused as in the reference.
+__global__ __launch_bounds__(256) void k_score_f(const double* __restrict__ pd, int n,
                                                  const float* __restrict__ F_all, int iterations, int pairs,
                                                  double sigma, float* __restrict__ score_out) {
-    __shared__ float4 s_pt[kScorePairs][kScoreChunk];
-    const ScoreSpan sp = score_span(iterations, pairs);
-    const bool live = sp.live;
-    const float* Fp = F_all + ((size_t)sp.pair * iterations + sp.it) * 9;
+    __shared__ double2 s_term[2][kScoreChunkF][64];
+    __shared__ double s_score[64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const ScoreLane sl = score_lane(iterations, pairs);
+    const float* Fp = F_all + ((size_t)sl.pair * iterations + sl.it) * 9;
     const double f11 = Fp[0], f12 = Fp[1], f13 = Fp[2], f21 = Fp[3], f22 = Fp[4], f23 = Fp[5], f31 = Fp[6],
                  f32 = Fp[7], f33 = Fp[8];
-    double score = 0;
     const double th = 3.841, th_score = 5.991;
     const double inv_sigma_square = 1.0 / (sigma * sigma);
-    for (int base = 0; base < n; base += kScoreChunk) {
-        const int cnt = min(kScoreChunk, n - base);
-        __syncthreads();
-        score_stage(s_pt, sp, pts, ref, n, base, cnt);
-        __syncthreads();
-        if (live)
-            for (int i = 0; i < cnt; i++) {
-                const float4 q = s_pt[sp.slot][i];
-                const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
-                const double a2 = f11 * u1 + f12 * v1 + f13;
-                const double b2 = f21 * u1 + f22 * v1 + f23;
-                const double c2 = f31 * u1 + f32 * v1 + f33;
-                const double num2 = a2 * u2 + b2 * v2 + c2;
-                const double sd1 = num2 * num2 / (a2 * a2 + b2 * b2);
-                const double chi1 = sd1 * inv_sigma_square;
-                if (!(chi1 > th)) score += th_score - chi1;
-                const double a1 = f11 * u2 + f21 * v2 + f31;
-                const double b1 = f12 * u2 + f22 * v2 + f32;
-                const double c1 = f13 * u2 + f23 * v2 + f33;
-                const double num1 = a1 * u1 + b1 * v1 + c1;
-                const double sd2 = num1 * num1 / (a1 * a1 + b1 * b1);
-                const double chi2 = sd2 * inv_sigma_square;
-                if (!(chi2 > th)) score += th_score - chi2;
+    if (wv == 0) s_score[lane] = 0.0;
+    constexpr int kPer = kScoreChunkF / 4;
+    // the two terms of one correspondence: (u1, v1) in the reference frame, (u2, v2) in the current frame
+    auto term = [&](double4 q) {
+        const double u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
+        const double a2 = __builtin_fma(f12, v1, f11 * u1) + f13;
+        const double b2 = __builtin_fma(f22, v1, f21 * u1) + f23;
+        const double c2 = __builtin_fma(f32, v1, f31 * u1) + f33;
+        const double num2 = a2 * u2 + b2 * v2 + c2;
+        const double sd1 = num2 * num2 / (a2 * a2 + b2 * b2);
+        const double chi1 = sd1 * inv_sigma_square;
+        const double a1 = __builtin_fma(f21, v2, f11 * u2) + f31;
+        const double b1 = __builtin_fma(f22, v2, f12 * u2) + f32;
+        const double c1 = __builtin_fma(f23, v2, f13 * u2) + f33;
+        const double num1 = a1 * u1 + b1 * v1 + c1;
+        const double sd2 = num1 * num1 / (a1 * a1 + b1 * b1);
+        const double chi2 = sd2 * inv_sigma_square;
+        return make_double2(chi1 > th ? 0.0 : th_score - chi1, chi2 > th ? 0.0 : th_score - chi2);
+    };
+    auto body = [&](auto uniform_tag) {
+        // UNIFORM: every lane has the same pair, whose index sits in a scalar register - the addresses then do not
+        // depend on the lane and the records come through the scalar cache
+        const int use = decltype(uniform_tag)::value ? __builtin_amdgcn_readfirstlane(sl.pair) : sl.pair;
+        const double4* rec = (const double4*)(pd + (size_t)use * n * 4);
+        int chunk = 0;
+        for (int base = 0; base < n; base += kScoreChunkF, chunk++) {
+            const int buf = chunk & 1;
+            const int c0 = base + wv * kPer;
+            if (base + kScoreChunkF <= n) {
+                // a whole chunk: the wavefront's records are fetched together, then evaluated
+                double4 q[kPer];
+#pragma unroll
+                for (int j = 0; j < kPer; j++) q[j] = rec[c0 + j];
+#pragma unroll
+                for (int j = 0; j < kPer; j++) s_term[buf][wv * kPer + j][lane] = term(q[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPer; j++)
+                    if (c0 + j < n) s_term[buf][wv * kPer + j][lane] = term(rec[c0 + j]);
             }
+            __syncthreads();
+            // this chunk's additions: the wavefronts take turns; the one whose turn it is finishes before it starts
+            // on the next chunk, and so before the next barrier, after which the following wavefront takes over
+            if (wv == (chunk & 3)) {
+                double score = s_score[lane];
+                const int cnt = min(kScoreChunkF, n - base);
+                for (int cc = 0; cc < cnt; cc++) {
+                    const double2 t = s_term[buf][cc][lane];
+                    score += t.x;
+                    score += t.y;
+                }
+                s_score[lane] = score;
+            }
+        }
+    };
+    // every wavefront of the workgroup meets the same barriers whichever form it takes: the trip counts are equal
+    if (__all(sl.pair == __builtin_amdgcn_readfirstlane(sl.pair))) body(std::true_type{});
+    else body(std::false_type{});
+    __syncthreads();
+    if (wv == 0 && sl.live) score_out[(size_t)sl.pair * iterations + sl.it] = (float)s_score[lane];
+}
+
+// 1.0f / x, correctly rounded.  v_rcp_f32 followed by one fused correction step gives exactly that whenever
+// 2^-120 <= |x| <= 2^120 (checked on gfx950 for every one of the 2^32 bit patterns, tools/rcp_exact.hip): three
+// instructions instead of the ten of the general division.  The short form is taken only when every lane of the
+// wavefront is inside that range (one test per wavefront, no divergence); otherwise all lanes divide.
+#ifndef ORBX_H_RCP
+#define ORBX_H_RCP 1
+#endif
+__device__ __forceinline__ float recip_ieee(float x) {
+#if ORBX_H_RCP
+    const unsigned ab = __float_as_uint(x) & 0x7fffffffu;
+    if (__all(ab - 0x03800000u <= 0x7b800000u - 0x03800000u)) {
+        const float r = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, r, 1.0f);
+        return __builtin_fmaf(r, e, r);
     }
-    if (live) score_out[(size_t)sp.pair * iterations + sp.it] = (float)score;
+#endif
+    return 1.0f / x;
 }
 
 // K12H: Initializer::checkHomographyScore (Initializer.cpp:501-585); fp32.  The reference writes the reciprocal as
@@ -778,42 +877,70 @@ __global__ __launch_bounds__(256) void k_score_h(const float* __restrict__ pts, 
                                                  const float* __restrict__ H_all, const float* __restrict__ Hinv_all,
                                                  int iterations, int pairs, double sigma,
                                                  float* __restrict__ score_out) {
-    __shared__ float4 s_pt[kScorePairs][kScoreChunk];
-    const ScoreSpan sp = score_span(iterations, pairs);
-    const bool live = sp.live;
-    const float* Hp = H_all + ((size_t)sp.pair * iterations + sp.it) * 9;
-    const float* Ip = Hinv_all + ((size_t)sp.pair * iterations + sp.it) * 9;
+    __shared__ float2 s_term[2][kScoreChunk][64];
+    __shared__ float s_score[64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const ScoreLane sl = score_lane(iterations, pairs);
+    const float* Hp = H_all + ((size_t)sl.pair * iterations + sl.it) * 9;
+    const float* Ip = Hinv_all + ((size_t)sl.pair * iterations + sl.it) * 9;
     const float h11 = Hp[0], h12 = Hp[1], h13 = Hp[2], h21 = Hp[3], h22 = Hp[4], h23 = Hp[5], h31 = Hp[6], h32 = Hp[7],
                 h33 = Hp[8];
     const float i11 = Ip[0], i12 = Ip[1], i13 = Ip[2], i21 = Ip[3], i22 = Ip[4], i23 = Ip[5], i31 = Ip[6], i32 = Ip[7],
                 i33 = Ip[8];
-    float score = 0;
     const float th = 5.991;
     const float invSigmaSquare = 1.0 / (sigma * sigma);
-    for (int base = 0; base < n; base += kScoreChunk) {
-        const int cnt = min(kScoreChunk, n - base);
-        __syncthreads();
-        score_stage(s_pt, sp, pts, ref, n, base, cnt);
-        __syncthreads();
-        if (live)
-            for (int i = 0; i < cnt; i++) {
-                const float4 q = s_pt[sp.slot][i];
-                const float u1 = q.x, v1 = q.y, u2 = q.z, v2 = q.w;
-                const float w2in1inv = 1.0f / (i31 * u2 + i32 * v2 + i33);
-                const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
-                const float v2in1 = (i21 * u2 + i22 * v2 + i23) * w2in1inv;
-                const float sq1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
-                const float chi1 = sq1 * invSigmaSquare;
-                if (!(chi1 > th)) score += th - chi1;
-                const float w1in2inv = 1.0f / (h31 * u1 + h32 * v1 + h33);
-                const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
-                const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
-                const float sq2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
-                const float chi2 = sq2 * invSigmaSquare;
-                if (!(chi2 > th)) score += th - chi2;
+    if (wv == 0) s_score[lane] = 0.f;
+    constexpr int kPer = kScoreChunk / 4;
+    auto term = [&](float2 rp, float2 cp) {
+        const float u1 = rp.x, v1 = rp.y, u2 = cp.x, v2 = cp.y;
+        const float w2in1inv = recip_ieee(i31 * u2 + i32 * v2 + i33);
+        const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
+        const float v2in1 = (i21 * u2 + i22 * v2 + i23) * w2in1inv;
+        const float sq1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
+        const float chi1 = sq1 * invSigmaSquare;
+        const float w1in2inv = recip_ieee(h31 * u1 + h32 * v1 + h33);
+        const float u1in2 = (h11 * u1 + h12 * v1 + h13) * w1in2inv;
+        const float v1in2 = (h21 * u1 + h22 * v1 + h23) * w1in2inv;
+        const float sq2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
+        const float chi2 = sq2 * invSigmaSquare;
+        return make_float2(chi1 > th ? 0.f : th - chi1, chi2 > th ? 0.f : th - chi2);
+    };
+    auto body = [&](auto uniform_tag) {
+        const PairPoints<decltype(uniform_tag)::value> pp(pts, ref, n, sl.pair);
+        int chunk = 0;
+        for (int base = 0; base < n; base += kScoreChunk, chunk++) {
+            const int buf = chunk & 1;
+            const int c0 = base + wv * kPer;
+            if (base + kScoreChunk <= n) {
+                // a whole chunk: the wavefront's points are fetched together, then evaluated
+                float2 rp[kPer], cp[kPer];
+#pragma unroll
+                for (int j = 0; j < kPer; j++) { rp[j] = pp.r2[c0 + j]; cp[j] = pp.p2[c0 + j]; }
+#pragma unroll
+                for (int j = 0; j < kPer; j++) s_term[buf][wv * kPer + j][lane] = term(rp[j], cp[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kPer; j++)
+                    if (c0 + j < n) s_term[buf][wv * kPer + j][lane] = term(pp.r2[c0 + j], pp.p2[c0 + j]);
             }
-    }
-    if (live) score_out[(size_t)sp.pair * iterations + sp.it] = score;
+            __syncthreads();
+            if (wv == (chunk & 3)) {
+                float score = s_score[lane];
+                const int cnt = min(kScoreChunk, n - base);
+                for (int cc = 0; cc < cnt; cc++) {
+                    const float2 t = s_term[buf][cc][lane];
+                    score += t.x;
+                    score += t.y;
+                }
+                s_score[lane] = score;
+            }
+        }
+    };
+    if (__all(sl.pair == __builtin_amdgcn_readfirstlane(sl.pair))) body(std::true_type{});
+    else body(std::false_type{});
+    __syncthreads();
+    if (wv == 0 && sl.live) score_out[(size_t)sl.pair * iterations + sl.it] = s_score[lane];
 }
 
 // Winner selection and inlier flags (best_out: winning iteration, -1 when no hypothesis scored above 0, -2 when

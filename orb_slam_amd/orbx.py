@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx.so")
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "liborbx.so")   # ORBX_LIB: an experimental build
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -33,7 +33,7 @@ SYMBOLS = [
     "orbx_feeder_start_memory", "orbx_feeder_next",
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
     "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream", "orbx_matcher_set_hamming_kernel",
-    "orbx_normalize_points", "orbx_fundamental_npt", "orbx_homography_dlt",
+    "orbx_normalize_points", "orbx_fundamental_npt", "orbx_homography_dlt", "orbx_ransac_set_fork",
 ]
 
 
@@ -621,6 +621,9 @@ class Ransac:
 
     def set_stream(self, stream_ptr):
         _check(lib().orbx_ransac_set_stream(self._h, C.c_void_p(stream_ptr)), "orbx_ransac_set_stream")
+
+    def set_fork(self, enabled):
+        _check(lib().orbx_ransac_set_fork(self._h, 1 if enabled else 0), "orbx_ransac_set_fork")
 
     def recover_pose_batch(self, F, K, pts, ref, pair_start):
         """F: pairs x 3 x 3 float32, K: 3 x 3 float32, pts / ref: total x 2 float64, pair_start: pairs + 1."""

@@ -22,6 +22,8 @@ d_F = torch.empty((P, 9), dtype=torch.float32, device=dev); d_H = torch.empty_li
 d_if = torch.empty((P, n), dtype=torch.uint8, device=dev); d_ih = torch.empty_like(d_if)
 d_sc = torch.empty((P, 2), dtype=torch.float32, device=dev); d_b = torch.empty((P, 2), dtype=torch.int32, device=dev)
 rs = orbx.Ransac()
+if os.environ.get("RANSAC_NO_FORK"):
+    rs.set_fork(False)   # every kernel alone on the chip
 def step():
     rs.fh_batch(d_pts.data_ptr(), d_ref.data_ptr(), n, d_sets.data_ptr(), it, P, 1.0, d_F.data_ptr(), d_H.data_ptr(),
                 d_if.data_ptr(), d_ih.data_ptr(), d_sc.data_ptr(), d_b.data_ptr())
