@@ -159,6 +159,9 @@ def main():
                     help="frames per GPU of the 4K extraction leg (3840x2160 gray, 8000 kp, 12 levels; 0 = skip)")
     ap.add_argument("--fed-frames", type=int, default=1024,
                     help="frames of the host-fed leg (PCIe-inclusive extraction rate, N = 1 only; 0 = skip)")
+    ap.add_argument("--pyramid-kernel", type=int, default=0,
+                    help="0 / 1: level by level (the default), 2: the one-pass kernel")
+    ap.add_argument("--pyramid-rows", type=int, default=0, help="image rows per step of the one-pass pyramid kernel")
     ap.add_argument("--profile-round", default="r02", help="prefix of the PMC summaries under profiles/ to quote")
     args = ap.parse_args()
 
@@ -220,6 +223,8 @@ def main():
             # with one batch in flight the blur runs beside the latency-bound middle of its own batch; with several, the
             # other batches fill those gaps and the blur runs in line
             self.ex.set_blur_fork(max(1, args.streams) == 1)
+            if args.pyramid_kernel or args.pyramid_rows:
+                self.ex.set_pyramid_kernel(args.pyramid_kernel, args.pyramid_rows)
             self.mt = orbx.Matcher(device=local_rank)
             self.mt.set_stream(self.tstream.cuda_stream)
             self.sf = self.ex.scale_tables()[1]

@@ -116,6 +116,14 @@ orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redon
 /* Switches the reuse of the uploaded image and its pyramid between orbx_detect and orbx_compute (default on). */
 orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled);
 
+/* No counterpart in the reference: which kernels build the pyramid (cv::ORB's cvtColor + resize chain).  kind 0
+   (default) and 1: level by level - gray conversion, then one launch per level; 2: the one-pass kernel whenever the
+   geometry suits it - one workgroup per frame reads the image once and writes every level, the rows in flight kept
+   in LDS rings, one launch per batch (it moves less than half the bytes but measures slower on 792 VGA frames, 0.98
+   against 0.77 ms, which is why it is not the default).  rows_per_step > 0 sets how many image rows a step of the
+   one-pass kernel converts (default 8).  Results are identical. */
+orbx_status orbx_extractor_set_pyramid_kernel(orbx_extractor* h, int kind, int rows_per_step);
+
 /* Camera model of Camera::undistortPoints (src/geometry/camera.cpp:97-126 -> cv::undistortPoints with P = K).
    Intrinsics and distortion as the reference holds them (cv::Mat_<float> widened to double). */
 typedef struct { double fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_camera;
@@ -447,6 +455,15 @@ orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, in
 /* The same on the device, by the wave-parallel form the batch extractor uses (n <= 8192). */
 orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int n, int n_points, int32_t* perm_out,
                                              int* new_n);
+
+/* Test hook (no counterpart in the reference), host only: plans the one-pass pyramid kernel for an image size
+   (which rows every level emits in which step, the depth of every LDS ring), checks the plan against its rings, and
+   - with image and atlas non-NULL - executes the same tables on the CPU.  info[4] = steps, LDS bytes, atlas width,
+   atlas height.  ORBX_UNSUPPORTED when the geometry does not suit that kernel (the extractor then builds the pyramid
+   level by level). */
+orbx_status orbx_selftest_stream_pyramid(const orbx_extractor_params* params, const uint8_t* image, int width,
+                                         int height, int stride, int channels, int rows_per_step, size_t max_lds_bytes,
+                                         uint8_t* atlas, size_t atlas_capacity, int32_t* info);
 
 /* Measurement hook (no counterpart in the reference): the vector issue rate this GPU sustains right now, in
    wave-instructions per second over the whole chip, for one instruction mix: kind 0 = v_add_u32, 1 = v_xor_b32 +

@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "extract_types.h"
+#include "pyramid_stream.h"
 #include "orbx.h"
 #include "stdsel.h"
 
@@ -365,6 +366,225 @@ __global__ __launch_bounds__(256) void k_resize_strip_sub(uint8_t* __restrict__ 
             for (int j = 0; j < 4; j++)
                 if (ok[j]) d[j] = (uint8_t)(out >> (8 * j));
         }
+    }
+}
+
+// K1+K2 in one pass (see pyramid_stream.h): one workgroup per frame walks the image top to bottom in steps; in a step
+// level 0 converts its next rows to gray and every level l >= 1 emits the rows whose two source rows of level l-1
+// were completed by earlier steps, reading them from level l-1's LDS ring.  Each emitted row goes to the atlas (with
+// its reflect-101 copy in the border where it has one) and into the level's own ring for the level above.  One
+// barrier per step: a step only reads ring rows that earlier steps wrote, and the host has checked that no row
+// written in a step shares a slot with a row the same step reads.
+// The resize arithmetic is that of k_resize_strip: the four left and four right samples of a lane's four pixels
+// lined up with v_perm from three source dwords, Q8 horizontal sums by v_dot2_u32_u16, vertical blend and rounding
+// by blend_rows_q8 - here with both source rows filtered per output row (the filtered rows are not kept: a ring of
+// 16-bit sums would double the LDS).
+__device__ __forceinline__ uint2 hfilter_q8(unsigned d0, unsigned d1, unsigned d2, unsigned sel, unsigned stepmask,
+                                            const unsigned (&wgt)[4]) {
+    const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, 1), e1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+    const unsigned A4 = __builtin_amdgcn_perm(d1, d0, sel);
+    unsigned B4 = __builtin_amdgcn_perm(e1, e0, sel);
+    B4 = (B4 & stepmask) | (A4 & ~stepmask);
+    const unsigned h0 = udot2_u16(__builtin_amdgcn_perm(B4, A4, 0x0c040c00u), wgt[0], 0u);
+    const unsigned h1 = udot2_u16(__builtin_amdgcn_perm(B4, A4, 0x0c050c01u), wgt[1], 0u);
+    const unsigned h2 = udot2_u16(__builtin_amdgcn_perm(B4, A4, 0x0c060c02u), wgt[2], 0u);
+    const unsigned h3 = udot2_u16(__builtin_amdgcn_perm(B4, A4, 0x0c070c03u), wgt[3], 0u);
+    return make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));  // each sum <= 255 * 256
+}
+
+// Work is bound to threads once, so that nothing a lane needs in a step comes from global memory at the moment it
+// is needed: every thread OWNS up to kStreamColsPerThread columns (aligned dwords) of the levels >= 1 - the list of
+// all levels' columns dealt round-robin, so each thread has a wide and a narrow level - and keeps their coefficient
+// records in registers for the whole frame; the row records of the rows a step emits are fetched one step ahead by a
+// few threads and handed over through a small LDS cache; the image bytes level 0 converts in step s + 1 are loaded
+// into registers at the top of step s.  What is left on the critical path of a step is LDS and arithmetic.
+// (four wavefronts per SIMD = four frames per CU: with 792 frames on 256 CUs every frame must be resident at once)
+__global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pyramid_stream(const uint8_t* __restrict__ img, size_t frame_stride,
+                                                                   int stride, int ch, uint8_t* __restrict__ atlas,
+                                                                   size_t atlas_bytes, StreamParams P,
+                                                                   const StreamCol* __restrict__ cols,
+                                                                   const StreamRow* __restrict__ rows,
+                                                                   const short* __restrict__ sched) {
+    extern __shared__ __align__(16) unsigned s_ring[];
+    const int tid = threadIdx.x;
+    const uint8_t* frame = img + (size_t)blockIdx.x * frame_stride;
+    uint8_t* plane = atlas + (size_t)blockIdx.x * atlas_bytes;
+    const int aw = P.aw, nl = P.nlevels, rc_rows = P.rc_rows;
+    // behind the rings: [2] x { row records [nl][rc_rows], row ranges [kMaxLevels] as (first, count) }
+    StreamRow* s_rows = (StreamRow*)(s_ring + P.ring_dwords);
+    int2* s_range = (int2*)(s_rows + 2 * nl * rc_rows);
+
+    // ---- the columns this thread owns
+    StreamCol col[kStreamColsPerThread];
+    int c_level[kStreamColsPerThread], c_src[kStreamColsPerThread], c_src_pitch[kStreamColsPerThread],
+        c_own[kStreamColsPerThread], c_own_pitch[kStreamColsPerThread], c_gx[kStreamColsPerThread],
+        c_gy[kStreamColsPerThread];
+#pragma unroll
+    for (int k = 0; k < kStreamColsPerThread; k++) {
+        const int f = tid + kStreamThreads * k;
+        c_level[k] = 0;   // level 0 owns no column here: "nothing to do"
+        if (f < P.total_cols) {
+            int l = 1;
+            while (l + 1 < nl && f >= P.L[l + 1].col_off) l++;
+            col[k] = cols[f];
+            if (col[k].ok != 0u) {
+                const int j = f - P.L[l].col_off;
+                c_level[k] = l;
+                c_src[k] = P.L[l - 1].lds_off + col[k].j0;
+                c_src_pitch[k] = P.L[l - 1].pitch;
+                c_own[k] = P.L[l].depth > 0 ? P.L[l].lds_off + j : -1;
+                c_own_pitch[k] = P.L[l].pitch;
+                c_gx[k] = P.L[l].ax_begin + 4 * j;
+                c_gy[k] = P.L[l].ay;
+            }
+        }
+    }
+
+    // ---- level 0 items of a step: 16-pixel groups inside the image, single pixels in the reflected border
+    const StreamLevel& L0 = P.L[0];
+    const int rx = L0.ax, x_first = rx - P.border, x_last = rx + L0.w + P.border;
+    static_assert(kStreamGrayItems == 2, "two named register sets below");
+    // the image bytes of one of this thread's two 16-pixel groups (a, b, c: 48 bytes of BGR, or a: 16 gray bytes) and
+    // of one of its two border pixels (B | G << 8 | R << 16, or the gray value)
+    struct GrayRegs { uint4 a, b, c; unsigned e; };
+    GrayRegs g0 = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), 0u}, g1 = g0;
+    auto gray_fetch_item = [&](int s, int m, GrayRegs gr) __attribute__((always_inline)) {
+        const int y0 = sched[(size_t)s * nl * 2], ny = sched[(size_t)s * nl * 2 + 1] - y0;
+        const int i = tid + kStreamThreads * m;
+        if (i < ny * P.n_in) {
+            const int ry = (int)(__umul24((unsigned)i, P.magic_in) >> 20);
+            const int q = P.q_in0 + i - ry * P.n_in;
+            const int sx = L0.ax_begin + 16 * q - rx;
+            const uint8_t* row = frame + (size_t)(y0 + ry) * stride;
+            if (ch == 1) gr.a = load_u128_any(row + sx);
+            else {
+                const uint8_t* sp = row + (size_t)sx * 3;
+                gr.a = load_u128_any(sp);
+                gr.b = load_u128_any(sp + 16);
+                gr.c = load_u128_any(sp + 32);
+            }
+        }
+        if (i < ny * P.n_edge) {
+            const int ry = (int)(__umul24((unsigned)i, P.magic_edge) >> 20);
+            const int e = i - ry * P.n_edge;
+            const int ax = L0.ax_begin + (e < P.left_edge ? e : e - P.left_edge + P.q_in1 * 16);
+            gr.e = 0u;
+            if (ax >= x_first && ax < x_last) {
+                const uint8_t* sp = frame + (size_t)(y0 + ry) * stride + (size_t)reflect101(ax - rx, L0.w) * ch;
+                gr.e = ch == 1 ? (unsigned)sp[0] : ((unsigned)sp[0] | ((unsigned)sp[1] << 8) | ((unsigned)sp[2] << 16));
+            }
+        }
+        return gr;
+    };
+    auto gray_fetch = [&](int s) __attribute__((always_inline)) {   // the image bytes of step s into registers
+        g0 = gray_fetch_item(s, 0, g0);
+        g1 = gray_fetch_item(s, 1, g1);
+    };
+    // the row records and row ranges of step s, fetched by the first nl * rc_rows (and nl) threads
+    struct RowRegs { StreamRow row; int2 range; };
+    RowRegs nx = {StreamRow{0u, 0, -1, 0}, make_int2(0, 0)};
+    auto rows_fetch = [&](int s, RowRegs r) __attribute__((always_inline)) {
+        if (tid < nl * rc_rows) {
+            const int l = tid / rc_rows, i = tid - l * rc_rows;
+            const int y0 = sched[(size_t)(s * nl + l) * 2], y1 = sched[(size_t)(s * nl + l) * 2 + 1];
+            if (y0 + i < y1) r.row = rows[P.L[l].row_off + y0 + i];
+        }
+        if (tid < nl) {
+            const int y0 = sched[(size_t)(s * nl + tid) * 2], y1 = sched[(size_t)(s * nl + tid) * 2 + 1];
+            r.range = make_int2(y0, y1 - y0);
+        }
+        return r;
+    };
+    auto rows_publish = [&](int s, const RowRegs r) __attribute__((always_inline)) {
+        if (tid < nl * rc_rows) s_rows[(s & 1) * nl * rc_rows + tid] = r.row;
+        if (tid < nl) s_range[(s & 1) * kMaxLevels + tid] = r.range;
+    };
+    gray_fetch(0);
+    nx = rows_fetch(0, nx);
+    rows_publish(0, nx);
+    __syncthreads();
+
+    for (int s = 0; s < P.n_steps; s++) {
+        const StreamRow* rcache = s_rows + (s & 1) * nl * rc_rows;
+        const int2* range = s_range + (s & 1) * kMaxLevels;
+        const bool more = s + 1 < P.n_steps;
+        if (more) nx = rows_fetch(s + 1, nx);   // in flight while this step works
+        // ---- level 0: the bytes fetched during the previous step
+        auto gray_emit_item = [&](int m, const GrayRegs& gr) __attribute__((always_inline)) {
+            const int y0 = range[0].x, ny = range[0].y;
+            const int i = tid + kStreamThreads * m;
+            if (i < ny * P.n_in) {
+                const int ry = (int)(__umul24((unsigned)i, P.magic_in) >> 20);
+                const int q = P.q_in0 + i - ry * P.n_in, y = y0 + ry;
+                const StreamRow r = rcache[ry];
+                const int ax = L0.ax_begin + 16 * q;
+                uint4 out;
+                if (ch == 1) out = gr.a;
+                else {
+                    const uint4 v0 = gr.a, v1 = gr.b, v2 = gr.c;
+                    out.x = gray4(v0.x, v0.y, v0.z);
+                    out.y = gray4(v0.w, v1.x, v1.y);
+                    out.z = gray4(v1.z, v1.w, v2.x);
+                    out.w = gray4(v2.y, v2.z, v2.w);
+                }
+                __builtin_memcpy(plane + (size_t)(L0.ay + y) * aw + ax, &out, 16);
+                if (r.mirror >= 0) __builtin_memcpy(plane + (size_t)r.mirror * aw + ax, &out, 16);
+                if (L0.depth > 0)
+                    *(uint4*)(s_ring + L0.lds_off + __umul24((r.slots >> 16) & 255u, (unsigned)L0.pitch) + 4 * q) = out;
+            }
+            if (i < ny * P.n_edge) {
+                const int ry = (int)(__umul24((unsigned)i, P.magic_edge) >> 20);
+                const int e = i - ry * P.n_edge, y = y0 + ry;
+                const int ax = L0.ax_begin + (e < P.left_edge ? e : e - P.left_edge + P.q_in1 * 16);
+                if (ax >= x_first && ax < x_last) {
+                    const StreamRow r = rcache[ry];
+                    const uint8_t v = (uint8_t)(ch == 1 ? gr.e : gray_of(gr.e & 255u, (gr.e >> 8) & 255u, (gr.e >> 16) & 255u));
+                    plane[(size_t)(L0.ay + y) * aw + ax] = v;
+                    if (r.mirror >= 0) plane[(size_t)r.mirror * aw + ax] = v;
+                    if (L0.depth > 0)
+                        ((uint8_t*)(s_ring + L0.lds_off + __umul24((r.slots >> 16) & 255u, (unsigned)L0.pitch)))[ax - L0.ax_begin] = v;
+                }
+            }
+        };
+        gray_emit_item(0, g0);
+        gray_emit_item(1, g1);
+        if (more) gray_fetch(s + 1);   // the loads return while the levels above are worked on
+        // ---- levels >= 1: this thread's columns, every row their level emits in this step
+        auto emit_column = [&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value;   // a constant: the column records stay in registers
+            const int l = c_level[k];
+            if (l == 0) return;
+            const int y0 = range[l].x, ny = range[l].y;
+            const StreamRow* rl = rcache + l * rc_rows;
+            for (int ry = 0; ry < ny; ry++) {
+                const StreamRow r = rl[ry];
+                const unsigned* ra = s_ring + c_src[k] + __umul24(r.slots & 255u, (unsigned)c_src_pitch[k]);
+                const unsigned* rb = s_ring + c_src[k] + __umul24((r.slots >> 8) & 255u, (unsigned)c_src_pitch[k]);
+                const uint2 ha = hfilter_q8(ra[0], ra[1], ra[2], col[k].sel, col[k].stepmask, col[k].wgt);
+                const uint2 hb = hfilter_q8(rb[0], rb[1], rb[2], col[k].sel, col[k].stepmask, col[k].wgt);
+                const unsigned out = blend_rows_q8(ha, hb, (unsigned)r.w1);
+                uint8_t* d = plane + (size_t)(c_gy[k] + y0 + ry) * aw + c_gx[k];
+                uint8_t* m = r.mirror >= 0 ? plane + (size_t)r.mirror * aw + c_gx[k] : nullptr;
+                if (col[k].ok == 15u) {
+                    *(unsigned*)d = out;
+                    if (m) *(unsigned*)m = out;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (col[k].ok & (1u << t)) {
+                            d[t] = (uint8_t)(out >> (8 * t));
+                            if (m) m[t] = (uint8_t)(out >> (8 * t));
+                        }
+                }
+                if (c_own[k] >= 0) s_ring[c_own[k] + __umul24((r.slots >> 16) & 255u, (unsigned)c_own_pitch[k])] = out;
+            }
+        };
+        static_assert(kStreamColsPerThread == 3, "one call per owned column");
+        emit_column(std::integral_constant<int, 0>{});
+        emit_column(std::integral_constant<int, 1>{});
+        emit_column(std::integral_constant<int, 2>{});
+        if (more) rows_publish(s + 1, nx);   // into the other buffer: nobody reads it before the barrier
+        __syncthreads();
     }
 }
 

@@ -1,5 +1,6 @@
 // Host-side logic of the orbx library (see host_logic.h).  Plain C++; no device code.
 #include "host_logic.h"
+#include "pyramid_stream.h"
 #include "stdsel.h"
 
 #include <algorithm>
@@ -157,6 +158,26 @@ orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, in
     const int m = orbx::stdsel::retain_best(a.data(), n, n_points);
     for (int i = 0; i < m; i++) perm_out[i] = a[i].idx;
     *new_n = m;
+    return ORBX_OK;
+}
+
+orbx_status orbx_selftest_stream_pyramid(const orbx_extractor_params* params, const uint8_t* image, int width,
+                                         int height, int stride, int channels, int rows_per_step, size_t max_lds_bytes,
+                                         uint8_t* atlas, size_t atlas_capacity, int32_t* info) {
+    if (!params || !info || width <= 0 || height <= 0 || (channels != 1 && channels != 3)) return ORBX_BAD_ARG;
+    orbx::HostGeometry hg;
+    orbx_status st = orbx::compute_geometry(*params, width, height, params->level_pyramid, hg);
+    if (st != ORBX_OK) return st;
+    orbx::StreamPlan sp;
+    info[2] = hg.g.atlas_w;
+    info[3] = hg.g.atlas_h;
+    if (!orbx::build_stream_plan(hg, width, height, rows_per_step, max_lds_bytes, sp)) return ORBX_UNSUPPORTED;
+    info[0] = sp.prm.n_steps;
+    info[1] = (int32_t)sp.lds_bytes;
+    if (!image || !atlas) return ORBX_OK;
+    if (atlas_capacity < hg.atlas_bytes || stride < width * channels) return ORBX_CAPACITY;
+    // an access outside the atlas or the rings would be a fault on the device: report it as such
+    if (!orbx::emulate_stream_pyramid(sp, image, stride, channels, atlas, hg.g.atlas_h)) return ORBX_DEVICE;
     return ORBX_OK;
 }
 

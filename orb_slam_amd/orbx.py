@@ -34,6 +34,7 @@ SYMBOLS = [
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
     "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream", "orbx_matcher_set_hamming_kernel",
     "orbx_normalize_points", "orbx_fundamental_npt", "orbx_homography_dlt", "orbx_ransac_set_fork",
+    "orbx_selftest_stream_pyramid", "orbx_extractor_set_pyramid_kernel",
 ]
 
 
@@ -231,6 +232,10 @@ class Extractor:
     def set_blur_fork(self, enabled):
         """Blur of a batch on the handle's side stream (default) or in line (several batches in flight)."""
         _check(lib().orbx_extractor_set_blur_fork(self._h, int(bool(enabled))), "orbx_extractor_set_blur_fork")
+
+    def set_pyramid_kernel(self, kind, rows_per_step=0):
+        """0 / 1: level by level, 2: the one-pass kernel whenever the geometry allows."""
+        _check(lib().orbx_extractor_set_pyramid_kernel(self._h, kind, rows_per_step), "orbx_extractor_set_pyramid_kernel")
 
     def set_image_cache(self, enabled):
         _check(lib().orbx_extractor_set_image_cache(self._h, int(enabled)), "orbx_extractor_set_image_cache")
@@ -586,6 +591,27 @@ def selftest_retain_best_device(keys, n_points, device=0):
     _check(lib().orbx_selftest_retain_best_device(device, _p(keys), len(keys), n_points, _p(perm), C.byref(n)),
            "orbx_selftest_retain_best_device")
     return perm[:n.value].copy()
+
+
+def selftest_stream_pyramid(params, image, rows_per_step=8, max_lds_bytes=65536, width=None, height=None):
+    """Plan of the one-pass pyramid kernel for an image size and, with an image, the plan executed on the CPU.
+    Returns (info dict, atlas or None); raises OrbxError(UNSUPPORTED) when the geometry does not suit the kernel."""
+    info = np.zeros(4, np.int32)
+    if image is None:
+        _check(lib().orbx_selftest_stream_pyramid(C.byref(params), None, width, height, width, 1, rows_per_step,
+                                                  C.c_size_t(max_lds_bytes), None, C.c_size_t(0), _p(info)),
+               "orbx_selftest_stream_pyramid")
+        atlas = None
+    else:
+        img, w, h, stride, ch = _img(image)
+        _check(lib().orbx_selftest_stream_pyramid(C.byref(params), None, w, h, stride, ch, rows_per_step,
+                                                  C.c_size_t(max_lds_bytes), None, C.c_size_t(0), _p(info)),
+               "orbx_selftest_stream_pyramid")
+        atlas = np.zeros((int(info[3]), int(info[2])), np.uint8)
+        _check(lib().orbx_selftest_stream_pyramid(C.byref(params), _p(img), w, h, stride, ch, rows_per_step,
+                                                  C.c_size_t(max_lds_bytes), _p(atlas), C.c_size_t(atlas.size), _p(info)),
+               "orbx_selftest_stream_pyramid")
+    return dict(steps=int(info[0]), lds_bytes=int(info[1]), atlas_w=int(info[2]), atlas_h=int(info[3])), atlas
 
 
 def probe_issue_rate(kind, device=0):

@@ -134,3 +134,36 @@ def test_no_fallback_without_library_or_gpu(monkeypatch):
             orbx.Extractor(n_key_points=100, level_pyramid=2, max_width=64, max_height=64)
         with pytest.raises(orbx.OrbxError):
             orbx.Matcher()
+
+
+def test_one_pass_pyramid_plan_executes_to_the_oracle_pyramid(oracle):
+    """The one-pass pyramid kernel only executes tables the host makes (rows per step and level, ring depths, per-column
+    and per-row coefficients).  Here the same tables run on the CPU: the result must be the oracle's pyramid, padded
+    rectangles included, for colour and gray images, odd sizes and several step heights; and geometries the kernel does
+    not suit must be refused, not mis-planned."""
+    from tests.conftest import synth_image
+    cases = [(synth_image(21, 640, 480, 3), 8, 8), (synth_image(22, 640, 480), 8, 4), (synth_image(23, 333, 257, 3), 4, 6),
+             (synth_image(24, 401, 299), 5, 5), (synth_image(25, 704, 480, 3), 8, 8), (synth_image(26, 880, 600), 5, 6)]
+    for img, nlevels, rows in cases:
+        prm = orbx.make_params(n_key_points=1000, level_pyramid=nlevels)
+        p = oracle.orb_params(nfeatures=1000, nlevels=nlevels)
+        info, atlas = orbx.selftest_stream_pyramid(prm, img, rows_per_step=rows, max_lds_bytes=160 * 1024)
+        oatlas, rects, _ = oracle.pyramid(p, img)
+        assert atlas.shape == oatlas.shape
+        for l, (rx, ry, rw, rh) in enumerate(rects):
+            b = 32
+            assert np.array_equal(atlas[ry - b:ry + rh + b, rx - b:rx + rw + b],
+                                  oatlas[ry - b:ry + rh + b, rx - b:rx + rw + b]), (img.shape, nlevels, rows, l)
+        assert info["steps"] >= img.shape[0] // rows and 0 < info["lds_bytes"] <= 160 * 1024
+    # the VGA / 8-level plan the batch path uses fits several workgroups per CU
+    prm = orbx.make_params(n_key_points=1000, level_pyramid=8)
+    info, _ = orbx.selftest_stream_pyramid(prm, None, rows_per_step=8, width=640, height=480)
+    assert info["lds_bytes"] <= 48 * 1024, info
+    # a level lower than twice the border, rings beyond the LDS allowed, more columns or more level-0 items per step
+    # than the workgroup's threads own: refused
+    for kw in (dict(width=150, height=120, rows_per_step=8), dict(width=640, height=480, rows_per_step=8, max_lds_bytes=4096),
+               dict(width=1280, height=720, rows_per_step=8, max_lds_bytes=160 * 1024),
+               dict(width=640, height=480, rows_per_step=32, max_lds_bytes=160 * 1024)):
+        with pytest.raises(orbx.OrbxError) as e:
+            orbx.selftest_stream_pyramid(prm, None, **kw)
+        assert e.value.status == orbx.UNSUPPORTED

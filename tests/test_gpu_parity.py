@@ -351,6 +351,58 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     ex.close()
 
 
+def test_one_pass_pyramid_kernel_bit_exact(oracle, test_images):
+    """The one-pass pyramid kernel (a workgroup per frame, every level from LDS rings, one launch per batch) against
+    the oracle's pyramid, padded rectangles included, and the whole batch extraction against the level-by-level
+    kernels: colour and gray, odd sizes, several step heights, and a batch of 130 frames."""
+    import torch
+    cases = [("vga_color", [test_images[0], test_images[1], synth_image(31, 640, 480, 3)], 8, 8),
+             ("vga_gray", [test_images[0][:, :, 1].copy(), synth_image(32, 640, 480)], 8, 4),
+             ("odd_color", [synth_image(33, 333, 257, 3), synth_image(34, 333, 257, 3)], 4, 6),
+             ("odd_gray", [synth_image(35, 401, 299), synth_image(36, 401, 299)], 5, 5),
+             ("wide", [synth_image(37, 704, 480, 3)], 8, 8)]
+    for name, frames, nlevels, rows in cases:
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else 3
+        p = oracle.orb_params(nfeatures=1000, nlevels=nlevels)
+        ex = orbx.Extractor(n_key_points=1000, level_pyramid=nlevels, max_width=w, max_height=h, max_batch=len(frames))
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        torch.cuda.synchronize()
+        res = {}
+        for kind in (1, 2):
+            ex.set_pyramid_kernel(kind, rows)
+            res[kind] = ex.extract_batch(dev.data_ptr(), len(frames), w * h * ch, w, h, w * ch, ch, 2000)
+            t = ex.last_timings()
+            assert (t["resize"] == 0) == (kind == 2), (name, kind, t)     # kind 2 really took the one-pass kernel
+            for f, img in enumerate(frames):
+                atlas = ex.read_plane(0, w, h, frame=f)
+                oatlas, rects, _ = oracle.pyramid(p, img)
+                for l, (rx, ry, rw, rh) in enumerate(rects):
+                    b = 32
+                    assert np.array_equal(atlas[ry - b:ry + rh + b, rx - b:rx + rw + b],
+                                          oatlas[ry - b:ry + rh + b, rx - b:rx + rw + b]), (name, kind, f, l)
+        (k1, c1, d1), (k2, c2, d2) = res[1], res[2]
+        assert np.array_equal(c1, c2), name
+        for f in range(len(frames)):   # slots beyond a frame's count hold whatever an earlier call left there
+            assert np.array_equal(k1[f, :c1[f]], k2[f, :c2[f]]) and np.array_equal(d1[f, :c1[f]], d2[f, :c2[f]]), (name, f)
+        ex.close()
+    # a large batch (more workgroups than CUs): what the oracle gives
+    frames = [test_images[i % 2] if i % 5 == 0 else synth_image(400 + i, 640, 480, 3) for i in range(130)]
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(frames))
+    ex.set_pyramid_kernel(2, 6)
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1500)
+    assert ex.last_timings()["resize"] == 0
+    p = oracle.orb_params(nfeatures=1000)
+    for f in (0, 1, 64, 127, 129):
+        ok_ = oracle.detect(p, frames[f])
+        ok2, od = oracle.compute(p, frames[f], ok_)
+        assert counts[f] == len(ok2) and np.array_equal(kps[f, :counts[f]], ok2.astype(orbx.KP_DTYPE))
+        assert np.array_equal(desc[f, :counts[f]], od)
+    ex.close()
+
+
 def test_compute_after_a_failed_batch(oracle, test_images):
     """A batch forks its blur onto a side stream; a batch that fails between the fork and the describe stage (host
     selection, more keypoints than the caller's capacity) must leave the handle clean: the next compute on the same
