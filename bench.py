@@ -498,9 +498,12 @@ def main():
         # one untimed block against the local key frames: the matcher's workspace is allocated on first use
         kfdb.match_frames_against_database(backend, kdesc, kcnt, kdesc[rows].contiguous(), kcnt[rows].contiguous(),
                                            frames=range(min(8, KF)), consume=lambda f, i, d: None)
+        # one untimed gather: the first collective on a process group sets up its communicator, and the first
+        # index_select of this shape allocates - neither belongs to the all-gather time reported below
+        gather_out = kfdb.gather_database(kdesc, kcnt, rows, dist if world > 1 else None)
         barrier()
         k0 = time.perf_counter()
-        db_desc, db_counts = kfdb.gather_database(kdesc, kcnt, rows, dist if world > 1 else None)
+        db_desc, db_counts = kfdb.gather_database(kdesc, kcnt, rows, dist if world > 1 else None, out=gather_out)
         torch.cuda.synchronize()
         k1 = time.perf_counter()
         kfdb.match_frames_against_database(backend, kdesc, kcnt, db_desc, db_counts, consume=lambda f, i, d: None)

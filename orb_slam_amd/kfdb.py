@@ -2,7 +2,8 @@
 
 Every rank extracts its own contiguous block of frames (no collective on that path).  Every `every`-th frame of the
 sequence is a key frame; the ranks replicate their key frames' descriptor blocks with ONE all-gather of uint8 rows
-(RCCL over xGMI on GPUs, gloo on CPU) plus one of the per-key-frame row counts, and then each rank matches each of
+into a preallocated buffer (RCCL over xGMI on GPUs, gloo on CPU) plus one of the per-key-frame row counts and one of
+the per-rank key-frame numbers, and then each rank matches each of
 its frames against every key frame of the database: per (frame, key frame) pair what CVORBMatcher::match returns
 (reference src/geometry/orb_matcher.cpp:671-677: for every query row the train row of minimum Hamming distance,
 lowest index on ties).
@@ -20,22 +21,47 @@ def keyframe_rows(first_global_index, n_local, every=10):
     return list(range(first, n_local, every))
 
 
-def gather_database(desc, counts, key_rows, dist=None):
+def gather_database(desc, counts, key_rows, dist=None, out=None):
     """desc: [frames, cap, 32] uint8 tensor, counts: [frames] int32 tensor (same device), key_rows: local indices.
-    Returns (db_desc [K, cap, 32], db_counts [K]) holding the key frames of all ranks in rank order.  Every rank must
-    contribute the same number of key frames (the sequence is dealt in equal blocks)."""
+    Returns (db_desc [K, cap, 32], db_counts [K]) holding the key frames of all ranks in rank order.
+
+    The ranks may hold different numbers of key frames (a sequence whose length is no multiple of the key-frame
+    spacing times the number of ranks): the per-rank numbers are gathered first, every rank pads its block to the
+    largest, ONE all_gather_into_tensor fills a [world * k_max, cap, 32] buffer in place (no per-rank list, no
+    concatenation copy), and the padding is dropped only when there is any.  `out`: a (descriptor buffer, count
+    buffer) pair from an earlier call to fill again when it is large enough - a caller that gathers every batch then
+    allocates nothing."""
     import torch
     rows = torch.as_tensor(key_rows, dtype=torch.long, device=desc.device)
-    local_desc = desc.index_select(0, rows).contiguous()
-    local_counts = counts.index_select(0, rows).contiguous()
-    if dist is None or not dist.is_initialized():
-        return local_desc, local_counts
+    k_local = len(key_rows)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return desc.index_select(0, rows).contiguous(), counts.index_select(0, rows).contiguous()
     world = dist.get_world_size()
-    out_d = [torch.empty_like(local_desc) for _ in range(world)]
-    out_c = [torch.empty_like(local_counts) for _ in range(world)]
-    dist.all_gather(out_d, local_desc)
-    dist.all_gather(out_c, local_counts)
-    return torch.cat(out_d, 0), torch.cat(out_c, 0)
+    cap = desc.shape[1]
+    per_rank = torch.empty(world, dtype=torch.int32, device=desc.device)
+    dist.all_gather_into_tensor(per_rank, torch.tensor([k_local], dtype=torch.int32, device=desc.device))
+    per_rank = per_rank.tolist()
+    k_max = max(per_rank)
+    if k_max == 0:
+        return desc[:0].contiguous(), counts[:0].contiguous()
+    send_d = torch.zeros((k_max, cap, 32), dtype=torch.uint8, device=desc.device)
+    send_c = torch.zeros(k_max, dtype=torch.int32, device=desc.device)
+    if k_local:
+        torch.index_select(desc, 0, rows, out=send_d[:k_local])
+        torch.index_select(counts, 0, rows, out=send_c[:k_local])
+    if out is not None and out[0].shape[0] >= world * k_max and out[0].shape[1:] == send_d.shape[1:] and \
+            out[0].device == desc.device:
+        all_d, all_c = out[0][:world * k_max], out[1][:world * k_max]
+    else:
+        all_d = torch.empty((world * k_max, cap, 32), dtype=torch.uint8, device=desc.device)
+        all_c = torch.empty(world * k_max, dtype=torch.int32, device=desc.device)
+    dist.all_gather_into_tensor(all_d, send_d)
+    dist.all_gather_into_tensor(all_c, send_c)
+    if all(k == k_max for k in per_rank):
+        return all_d, all_c
+    keep = torch.as_tensor([r * k_max + i for r, k in enumerate(per_rank) for i in range(k)], dtype=torch.long,
+                           device=desc.device)
+    return all_d.index_select(0, keep), all_c.index_select(0, keep)
 
 
 class HipBackend:

@@ -12,9 +12,10 @@ def shard_range(n_units, rank, world):
 
 def all_gather_descriptors(local_desc, dist):
     """Replicates per-rank descriptor blocks ([k_local, n, 32] uint8 torch tensors of equal shape) on every rank
-    (RCCL all-gather on GPUs, gloo on CPU).  Returns [world * k_local, n, 32]."""
+    (RCCL all-gather on GPUs, gloo on CPU), straight into one [world * k_local, n, 32] tensor."""
     import torch
     world = dist.get_world_size()
-    out = [torch.empty_like(local_desc) for _ in range(world)]
-    dist.all_gather(out, local_desc.contiguous())
-    return torch.cat(out, 0)
+    local = local_desc.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out
