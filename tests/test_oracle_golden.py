@@ -119,6 +119,23 @@ def test_descriptor_variants_do_not_close_the_gap(oracle, test_images):
                       "sigma1.5": 1000, "sigma1": 764}
 
 
+def test_bit_order_and_argument_order_do_not_close_the_gap(oracle, test_images):
+    """Two more readings of the same assertion, both about conventions rather than arithmetic: descriptor bits packed
+    MSB-first within a byte (the byte-difference metric weighs a bit by its position; the Hamming distance does not),
+    and the radius matcher called with the two images' keypoints and descriptors swapped.  1071, 1158 and (both) 1075:
+    none reaches 750..800.  With these the bounded search for a pin of the descriptor bits ends."""
+    r, _, _ = _radius_matcher_kat(oracle, test_images)
+    rev = np.array([int("{:08b}".format(i)[::-1], 2) for i in range(256)], np.uint8)
+    (k0, d0), (k1, d1) = r
+    counts = {}
+    for name, a, b, da, db in (("msb_first", k0, k1, rev[d0], rev[d1]), ("swapped", k1, k0, d1, d0),
+                               ("both", k1, k0, rev[d1], rev[d0])):
+        m = oracle.match_radius(a, b, da, db, 100.0)
+        assert len(m) >= 4500
+        counts[name] = len(oracle.filter_matches(m, len(da)))
+    assert counts == {"msb_first": 1071, "swapped": 1158, "both": 1075}
+
+
 def test_filtered_match_window_under_hamming_distance(oracle, test_images):
     # The same window IS met when the distance is the Hamming distance: ORBMatcher::match(descriptors,
     # ref_descriptors, matches, true) = cv::BFMatcher + filterMatches (orb_matcher.cpp:719-733) gives 776 on the
