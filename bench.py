@@ -391,6 +391,14 @@ def main():
         ransac = {"hypotheses_per_s": world * P * it * 2 * reps / rdt, "pairs": P, "iterations": it,
                   "correspondences": n, "stage_ms": rs.last_timings(),
                   "mean_inliers_h": float(d_ih.float().sum(1).mean().item())}
+        # the same kernels one after the other on one stream (after the timed region): each has the chip to itself,
+        # which is the duration a roofline fraction of a single kernel needs
+        rs.set_fork(False)
+        rstep()
+        rstep()
+        torch.cuda.synchronize()
+        ransac["stage_ms_alone"] = rs.last_timings()
+        rs.set_fork(True)
 
     # ---- issue-rate rooflines of the two halves that are bound by the vector pipes, not by HBM ----------------------
     # Peaks: nominal = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz lane-operations/s for single-cycle-class instructions
@@ -408,7 +416,7 @@ def main():
     roofline_ransac = None
     if ransac:
         P, n, it = ransac["pairs"], ransac["correspondences"], ransac["iterations"]
-        st = ransac["stage_ms"]
+        st = ransac["stage_ms_alone"]
         # lane-operations of the scorers per (hypothesis, correspondence): Initializer.cpp:410-438 (48 fp64 multiplies,
         # adds and compares + 2 fp64 divisions) and :552-577 (44 fp32 operations + 2 divisions)
         def entry(kernel, ms, ops, nominal, measured):
@@ -416,7 +424,8 @@ def main():
                  "achieved": ops / (ms * 1e-3) / 1e12, "peak": nominal / 1e12, "peak_measured": measured / 1e12,
                  "unit": "T lane-ops/s", "frac": ops / (ms * 1e-3) / nominal,
                  "frac_of_measured": ops / (ms * 1e-3) / measured,
-                 "note": "duration measured while the other model's kernels share the chip (two streams)"}
+                 "note": "duration of the kernel alone on the chip (fundamental and homography chains one after the "
+                         "other); in the timed run the two chains share the chip on two streams"}
             k = sq.get(kernel)
             if k and "SQ_INSTS_VALU_per_launch" in k:
                 # every issued vector instruction (address arithmetic, divisions' expansions, LDS traffic included)

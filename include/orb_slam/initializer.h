@@ -11,8 +11,9 @@
  * the call site, where the caller has the full types, and they use exactly the accessors the reference uses
  * (Frame::nMatches / matches / featuresUndist, Initializer.cpp:44-53; Camera::intrinsicMatrix, :124,174,218).
  *
- * One additive seam: setRansacSets() injects the 8-index sets; without it they are drawn as in the reference
- * (std::shuffle seeded from std::random_device, cumulative over iterations, Initializer.cpp:261-277).
+ * Two additive seams: setRansacSets() injects the 8-index sets (without it they are drawn as in the reference:
+ * std::shuffle seeded from std::random_device, cumulative over iterations, Initializer.cpp:261-277), and
+ * setHomographyDecomposition() lets findRtWithHomography compute a pose where the reference always fails.
  */
 #pragma once
 
@@ -121,14 +122,43 @@ public:
 
     /**
      * Initializer::findRtWithHomography (Initializer.cpp:112-163).  The reference hands std::vector<cv::Point2d>
-     * to cv::filterHomographyDecompByVisibleRefpoints, which in OpenCV 3.4 asserts CV_32FC2 points; the
-     * cv::Exception is caught (:150-155) and the function returns false, so the reference never initialises from
-     * a homography.  That outcome is kept; no decomposition is computed.
+     * to cv::filterHomographyDecompByVisibleRefpoints, whose first statement in OpenCV 3.4 (calib3d
+     * homography_decomp.cpp) is CV_Assert(_beforeRectifiedPoints.type() == CV_32FC2 &&
+     * _afterRectifiedPoints.type() == CV_32FC2); the cv::Exception is caught (:150-155) and the function returns
+     * false, so the reference never initialises from a homography.  That outcome is the default here.
+     *
+     * Additive switch: after setHomographyDecomposition(true) the function computes what its statements describe -
+     * cv::decomposeHomographyMat, the visibility filter on the same coordinates held as floats, R and t of the
+     * first solution kept - on the device (orbx_recover_pose_homography_batch).  As in the reference it then
+     * returns true even when no solution is visible, leaving R and t untouched (triangulatePoints fails on the
+     * empty matrices).
      */
+    void setHomographyDecomposition(bool enabled) { decompose_homography_ = enabled; }
+
     bool findRtWithHomography(
-        const std::vector<cv::Point2d>&, const std::vector<cv::Point2d>&, cv::Mat&, cv::Mat&)
+        const std::vector<cv::Point2d>& inlier_points,
+        const std::vector<cv::Point2d>& inlier_ref_points,
+        cv::Mat& R,
+        cv::Mat& t)
     {
-        return false;
+        if (!decompose_homography_) return false;
+        const cv::Mat intrinsic_ = intrinsic();
+        if (homography_mat_.empty() || intrinsic_.empty()) return false; // cv::Exception path of the reference
+        const int32_t start[2] = {0, (int32_t)inlier_points.size()};
+        double r9[9], t3[3];
+        int32_t idx = -1;
+        orbx_status st = orbx_recover_pose_homography_batch(
+            handle_.get(), 1, homography_mat_.ptr<float>(), intrinsic_.ptr<float>(),
+            reinterpret_cast<const double*>(inlier_points.data()),
+            reinterpret_cast<const double*>(inlier_ref_points.data()), start, r9, t3, &idx, nullptr, nullptr);
+        if (st != ORBX_OK) return false;
+        if (idx >= 0) {
+            R.create(3, 3, CV_64F);
+            t.create(3, 1, CV_64F);
+            std::memcpy(R.data, r9, sizeof(r9));
+            std::memcpy(t.data, t3, sizeof(t3));
+        }
+        return true;
     }
 
     /** Initializer::findRtWithFundamental (Initializer.cpp:165-199): R (3x3) and t (3x1) as CV_64F. */
@@ -236,6 +266,7 @@ private:
     double sigma_, sigma_squared_;
     int iterations_;
     bool injected_ = false;
+    bool decompose_homography_ = false;
     std::vector<cv::Point2f> points_, ref_points_;
     std::vector<std::vector<size_t>> ransac_sets_;
     cv::Mat fundamental_mat_, homography_mat_;

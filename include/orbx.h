@@ -427,6 +427,24 @@ orbx_status orbx_recover_pose_batch(orbx_ransac* h, int n_pairs, const float* fu
                                     const double* points, const double* ref_points, const int32_t* pair_start,
                                     double* rotation, double* translation, int32_t* n_good);
 
+/* Initializer::findRtWithHomography (src/Initializer.cpp:112-163) for a batch of frame pairs, as it is written:
+   cv::decomposeHomographyMat(H, K) of OpenCV 3.4.9 in double (Hnorm = K^-1 H K over its middle singular value, the
+   analytic decomposition into [Ra, ta, na], [Ra, -ta, -na], [Rb, tb, nb], [Rb, -tb, -nb], or the single motion
+   [Hnorm, 0, 0] of a pure rotation), then cv::filterHomographyDecompByVisibleRefpoints(rotations, normals,
+   inlier_points, inlier_ref_points) and the first solution it keeps.  In the reference that second call never
+   completes: the function's first statement is CV_Assert(both point arrays are CV_32FC2), the reference hands it
+   std::vector<cv::Point2d> (CV_64FC2), the cv::Exception is caught (Initializer.cpp:150-155) and the function
+   returns false - which is what the Initializer facade does unless told otherwise.  This entry point computes what
+   the call sequence yields when the same coordinates arrive as floats (they are narrowed here, as Point2f would
+   hold them).  homography: n_pairs x 9 (row-major, float); points / ref_points / pair_start as for
+   orbx_recover_pose_batch.  Out: solution[p] = index of the chosen motion or -1 when none is visible (rotation and
+   translation rows are then zero; the reference would leave R and t empty and fail in triangulatePoints);
+   all_solutions (may be NULL): n_pairs x 4 x 15 doubles (R 9, t 3, n 3), n_solutions (may be NULL): 1 or 4. */
+orbx_status orbx_recover_pose_homography_batch(orbx_ransac* h, int n_pairs, const float* homography,
+                                               const float* intrinsics, const double* points, const double* ref_points,
+                                               const int32_t* pair_start, double* rotation, double* translation,
+                                               int32_t* solution, double* all_solutions, int32_t* n_solutions);
+
 /* Replaces Initializer::triangulatePoints (src/Initializer.cpp:201-252): cv::triangulatePoints with
    projection = K [R | t] and projection_ref = K [I | 0], each point divided by its fourth coordinate.
    points_3d: one (x, y, z) per correspondence, in the order of points. */

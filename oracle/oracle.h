@@ -190,6 +190,14 @@ int  orc_recover_pose_fundamental(const float* F9, const float* K9, const double
 /* Initializer::triangulatePoints. */
 void orc_triangulate_initial(const float* K9, const double* R9, const double* t3, const double* inlier_points,
                              const double* inlier_ref_points, int n, double* points3);
+/* src/Initializer.cpp:112-163 (findRtWithHomography): cv::decomposeHomographyMat and
+   cv::filterHomographyDecompByVisibleRefpoints of OpenCV 3.4.9; the last one is the whole function as it would run
+   if the filter accepted the reference's double points (it asserts on them, so the reference returns false). */
+int  orc_decompose_homography(const float* H9, const float* K9, double* R, double* t, double* nrm);
+int  orc_filter_homography_visible(const double* R, const double* nrm, int nsol, const float* before_points,
+                                   const float* after_points, int npoints, int32_t* solutions);
+int  orc_recover_pose_homography(const float* H9, const float* K9, const double* inlier_points,
+                                 const double* inlier_ref_points, int n, double* R9, double* t3);
 
 #ifdef __cplusplus
 }

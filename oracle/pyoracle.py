@@ -383,6 +383,40 @@ def recover_pose_fundamental(F, K, pts, ref):
     return R, t, good
 
 
+def decompose_homography(H, K):
+    """cv::decomposeHomographyMat -> (R [nsol, 3, 3], t [nsol, 3], normals [nsol, 3])."""
+    H = np.ascontiguousarray(H, np.float32).reshape(9)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    R, t, nrm = np.zeros((4, 3, 3)), np.zeros((4, 3)), np.zeros((4, 3))
+    lib().orc_decompose_homography.restype = C.c_int
+    nsol = lib().orc_decompose_homography(_p(H), _p(K), _p(R), _p(t), _p(nrm))
+    return R[:nsol], t[:nsol], nrm[:nsol]
+
+
+def filter_homography_visible(R, nrm, before, after):
+    """cv::filterHomographyDecompByVisibleRefpoints on CV_32FC2 points -> indices of the solutions kept."""
+    R = np.ascontiguousarray(R, np.float64).reshape(-1, 9)
+    nrm = np.ascontiguousarray(nrm, np.float64).reshape(-1, 3)
+    before = np.ascontiguousarray(before, np.float32).reshape(-1, 2)
+    after = np.ascontiguousarray(after, np.float32).reshape(-1, 2)
+    sols = np.zeros(4, np.int32)
+    lib().orc_filter_homography_visible.restype = C.c_int
+    kept = lib().orc_filter_homography_visible(_p(R), _p(nrm), len(R), _p(before), _p(after), len(before), _p(sols))
+    return sols[:kept]
+
+
+def recover_pose_homography(H, K, pts, ref):
+    """Initializer::findRtWithHomography with the filter's points as floats -> (R, t, index) or (None, None, -1)."""
+    H = np.ascontiguousarray(H, np.float32).reshape(9)
+    K = np.ascontiguousarray(K, np.float32).reshape(9)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+    ref = np.ascontiguousarray(ref, np.float64).reshape(-1, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    lib().orc_recover_pose_homography.restype = C.c_int
+    idx = lib().orc_recover_pose_homography(_p(H), _p(K), _p(pts), _p(ref), len(pts), _p(R), _p(t))
+    return (R, t, idx) if idx >= 0 else (None, None, -1)
+
+
 def triangulate_initial(K, R, t, pts, ref):
     K = np.ascontiguousarray(K, np.float32).reshape(9)
     R = np.ascontiguousarray(R, np.float64).reshape(9)

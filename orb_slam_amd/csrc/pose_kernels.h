@@ -346,4 +346,241 @@ __global__ __launch_bounds__(256) void k_triangulate_initial(const float* __rest
     dst[2] = q[2] * alpha + 0.;
 }
 
+// HomographyDecompInria::oppositeOfMinor (OpenCV 3.4 calib3d homography_decomp.cpp) with compile-time row / column.
+template <int ROW, int COL>
+__device__ __forceinline__ double opposite_of_minor(const double (&M)[9]) {
+    constexpr int x1 = COL == 0 ? 1 : 0, x2 = COL == 2 ? 1 : 2;
+    constexpr int y1 = ROW == 0 ? 1 : 0, y2 = ROW == 2 ? 1 : 2;
+    return M[y1 * 3 + x2] * M[y2 * 3 + x1] - M[y1 * 3 + x1] * M[y2 * 3 + x2];
+}
+
+// HomographyDecompInria::findRmatFrom_tstar_n: R = Hnorm (I - (2 / v) tstar n^T), negated when det(R) < 0.
+__device__ __forceinline__ void rmat_from_tstar_n(const double (&Hn)[9], const double (&tstar)[3], const double (&n)[3],
+                                                  double v, double (&R)[9]) {
+    const double alpha = 2 / v;
+    double M[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double ts = tstar[i] * alpha;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            s += ts * n[j];
+            M[i * 3 + j] = (i == j ? 1.0 : 0.0) - s;
+        }
+    }
+    mul33_f64(Hn, M, R);
+    if (det3_f64(R) < 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = R[i] * -1;
+    }
+}
+
+// Initializer::findRtWithHomography (reference src/Initializer.cpp:112-163) for one frame pair per wavefront:
+// cv::decomposeHomographyMat (Hnorm = K^-1 H K scaled by its middle singular value, the analytic four-solution
+// decomposition of S = Hnorm^T Hnorm - I) computed by every lane alike, then
+// cv::filterHomographyDecompByVisibleRefpoints with the lanes striding over the correspondences (coordinates narrowed
+// to float, as that function reads them), the verdict per solution formed by a ballot.
+// sol[pair] = 4 x (R 9, t 3, n 3); info[pair] = number of solutions, bit mask of the visible ones.
+__global__ __launch_bounds__(64) void k_pose_homography(const float* __restrict__ H_all, const float* __restrict__ K9,
+                                                        const double* __restrict__ pts, const double* __restrict__ ref,
+                                                        const int32_t* __restrict__ pair_start,
+                                                        double* __restrict__ sol, int32_t* __restrict__ info) {
+    const int pair = blockIdx.x;
+    const int lane = threadIdx.x;
+    double H[9], K[9], Kinv[9], Hn[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        H[i] = (double)H_all[(size_t)pair * 9 + i];
+        K[i] = (double)K9[i];
+    }
+    // Matx33d::inv(): adjugate times 1 / det, zeros for a singular matrix
+    double d = det3_f64(K);
+    if (d == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) Kinv[i] = 0;
+    } else {
+        d = 1 / d;
+        Kinv[0] = (K[4] * K[8] - K[5] * K[7]) * d;
+        Kinv[1] = (K[2] * K[7] - K[1] * K[8]) * d;
+        Kinv[2] = (K[1] * K[5] - K[2] * K[4]) * d;
+        Kinv[3] = (K[5] * K[6] - K[3] * K[8]) * d;
+        Kinv[4] = (K[0] * K[8] - K[2] * K[6]) * d;
+        Kinv[5] = (K[2] * K[3] - K[0] * K[5]) * d;
+        Kinv[6] = (K[3] * K[7] - K[4] * K[6]) * d;
+        Kinv[7] = (K[1] * K[6] - K[0] * K[7]) * d;
+        Kinv[8] = (K[0] * K[4] - K[1] * K[3]) * d;
+    }
+    mul33_f64(Kinv, H, Hn);
+    mul33_f64(Hn, K, Hn);
+    {
+        // removeScale: the singular values of Hnorm (the SVD front end works on the transpose), Hnorm / W[1]
+        double At[9], Vt[9], W[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) At[j * 3 + i] = Hn[i * 3 + j];
+        jacobi_square_f64<3>(At, Vt, W);
+        const double scale = 1.0 / W[1];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Hn[i] = Hn[i] * scale;
+    }
+    double S[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += Hn[k * 3 + i] * Hn[k * 3 + j];
+            S[i * 3 + j] = s;
+        }
+    S[0] -= 1.0;
+    S[4] -= 1.0;
+    S[8] -= 1.0;
+    double ninf = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double a = fabs(S[i]);
+        ninf = ninf < a ? a : ninf;
+    }
+    // the four motions: R (9), t (3), n (3) each
+    double Ra[9], Rb[9], ta[3], tb[3], na[3], nb[3];
+    int nsol;
+    if (ninf < 0.001) {
+        nsol = 1;
+#pragma unroll
+        for (int i = 0; i < 9; i++) Ra[i] = Rb[i] = Hn[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) ta[i] = tb[i] = na[i] = nb[i] = 0;
+    } else {
+        nsol = 4;
+        const double M00 = opposite_of_minor<0, 0>(S), M11 = opposite_of_minor<1, 1>(S);
+        const double M22 = opposite_of_minor<2, 2>(S);
+        const double rtM00 = sqrt(M00), rtM11 = sqrt(M11), rtM22 = sqrt(M22);
+        const double M01 = opposite_of_minor<0, 1>(S), M12 = opposite_of_minor<1, 2>(S);
+        const double M02 = opposite_of_minor<0, 2>(S);
+        const int e12 = M12 >= 0 ? 1 : -1, e02 = M02 >= 0 ? 1 : -1, e01 = M01 >= 0 ? 1 : -1;
+        const double nS00 = fabs(S[0]), nS11 = fabs(S[4]), nS22 = fabs(S[8]);
+        int indx = 0;
+        if (nS00 < nS11) {
+            indx = 1;
+            if (nS11 < nS22) indx = 2;
+        } else {
+            if (nS00 < nS22) indx = 2;
+        }
+        double npa[3], npb[3], Sii;
+        if (indx == 0) {
+            npa[0] = S[0], npb[0] = S[0];
+            npa[1] = S[1] + rtM22, npb[1] = S[1] - rtM22;
+            npa[2] = S[2] + e12 * rtM11, npb[2] = S[2] - e12 * rtM11;
+            Sii = S[0];
+        } else if (indx == 1) {
+            npa[0] = S[1] + rtM22, npb[0] = S[1] - rtM22;
+            npa[1] = S[4], npb[1] = S[4];
+            npa[2] = S[5] - e02 * rtM00, npb[2] = S[5] + e02 * rtM00;
+            Sii = S[4];
+        } else {
+            npa[0] = S[2] + e01 * rtM11, npb[0] = S[2] - e01 * rtM11;
+            npa[1] = S[5] + rtM00, npb[1] = S[5] - rtM00;
+            npa[2] = S[8], npb[2] = S[8];
+            Sii = S[8];
+        }
+        const double traceS = S[0] + S[4] + S[8];
+        const double v = 2.0 * sqrt(1 + traceS - M00 - M11 - M22);
+        const double ESii = Sii >= 0 ? 1 : -1;
+        const double r_2 = 2 + traceS + v, nt_2 = 2 + traceS - v;
+        const double r = sqrt(r_2), n_t = sqrt(nt_2);
+        double sa = 0, sb = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            sa += npa[i] * npa[i];
+            sb += npb[i] * npb[i];
+        }
+        const double ia = 1. / sqrt(sa), ib = 1. / sqrt(sb);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            na[i] = npa[i] * ia;
+            nb[i] = npb[i] * ib;
+        }
+        const double half_nt = 0.5 * n_t, esii_t_r = ESii * r;
+        double ta_star[3], tb_star[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            ta_star[i] = (nb[i] * esii_t_r - na[i] * n_t) * half_nt;
+            tb_star[i] = (na[i] * esii_t_r - nb[i] * n_t) * half_nt;
+        }
+        rmat_from_tstar_n(Hn, ta_star, na, v, Ra);
+        rmat_from_tstar_n(Hn, tb_star, nb, v, Rb);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                s0 += Ra[i * 3 + k] * ta_star[k];
+                s1 += Rb[i * 3 + k] * tb_star[k];
+            }
+            ta[i] = s0;
+            tb[i] = s1;
+        }
+    }
+    // visibility: solution q has the normal sign[q] * (na | nb) and the rotated normal R (that normal)
+    double rna[3], rnb[3], rnan[3], rnbn[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            s0 += Ra[i * 3 + k] * na[k];
+            s1 += Ra[i * 3 + k] * (na[k] * -1);
+            s2 += Rb[i * 3 + k] * nb[k];
+            s3 += Rb[i * 3 + k] * (nb[k] * -1);
+        }
+        rna[i] = s0; rnan[i] = s1; rnb[i] = s2; rnbn[i] = s3;
+    }
+    const int first = pair_start[pair], n = pair_start[pair + 1] - first;
+    bool ok0 = true, ok1 = true, ok2 = true, ok3 = true;
+    for (int j = lane; j < n; j += 64) {
+        const size_t o = 2 * (size_t)(first + j);
+        const double px = (double)(float)pts[o], py = (double)(float)pts[o + 1];
+        const double cx = (double)(float)ref[o], cy = (double)(float)ref[o + 1];
+        ok0 = ok0 && !(na[0] * px + na[1] * py + na[2] <= 0 || rna[0] * cx + rna[1] * cy + rna[2] <= 0);
+        ok1 = ok1 && !((na[0] * -1) * px + (na[1] * -1) * py + (na[2] * -1) <= 0 ||
+                       rnan[0] * cx + rnan[1] * cy + rnan[2] <= 0);
+        ok2 = ok2 && !(nb[0] * px + nb[1] * py + nb[2] <= 0 || rnb[0] * cx + rnb[1] * cy + rnb[2] <= 0);
+        ok3 = ok3 && !((nb[0] * -1) * px + (nb[1] * -1) * py + (nb[2] * -1) <= 0 ||
+                       rnbn[0] * cx + rnbn[1] * cy + rnbn[2] <= 0);
+    }
+    int mask = 0;
+    if (__ballot(!ok0) == 0) mask |= 1;
+    if (nsol == 4) {
+        if (__ballot(!ok1) == 0) mask |= 2;
+        if (__ballot(!ok2) == 0) mask |= 4;
+        if (__ballot(!ok3) == 0) mask |= 8;
+    }
+    if (lane == 0) {
+        double* o = sol + (size_t)pair * 60;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            o[i] = Ra[i];
+            o[15 + i] = Ra[i];
+            o[30 + i] = Rb[i];
+            o[45 + i] = Rb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            o[9 + i] = ta[i];
+            o[12 + i] = na[i];
+            o[24 + i] = ta[i] * -1;
+            o[27 + i] = na[i] * -1;
+            o[39 + i] = tb[i];
+            o[42 + i] = nb[i];
+            o[54 + i] = tb[i] * -1;
+            o[57 + i] = nb[i] * -1;
+        }
+        info[pair * 2] = nsol;
+        info[pair * 2 + 1] = mask;
+    }
+}
+
 }  // namespace orbx

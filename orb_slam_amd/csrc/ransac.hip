@@ -547,4 +547,44 @@ orbx_status orbx_triangulate_batch(orbx_ransac* h, int n_pairs, const float* int
     return ORBX_OK;
 }
 
+orbx_status orbx_recover_pose_homography_batch(orbx_ransac* h, int n_pairs, const float* homography,
+                                               const float* intrinsics, const double* points, const double* ref_points,
+                                               const int32_t* pair_start, double* rotation, double* translation,
+                                               int32_t* solution, double* all_solutions, int32_t* n_solutions) {
+    ORBX_ENTER(h);
+    if (!h || n_pairs < 0) return ORBX_BAD_ARG;
+    if (n_pairs == 0) return ORBX_OK;
+    if (!homography || !intrinsics || !pair_start || !rotation || !translation || !solution) return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int total = 0, longest = 0;
+    ORBX_TRY(upload_pose_points(h, n_pairs, points, ref_points, pair_start, &total, &longest));
+    ORBX_TRY(h->d_K.ensure(9));
+    ORBX_TRY(h->d_Fp.ensure((size_t)n_pairs * 9));
+    ORBX_TRY(h->d_cand.ensure((size_t)n_pairs * 60));
+    ORBX_TRY(h->d_good.ensure((size_t)n_pairs * 2));
+    ORBX_HIP(hipMemcpyAsync(h->d_K.p, intrinsics, sizeof(float) * 9, hipMemcpyHostToDevice, s));
+    ORBX_HIP(hipMemcpyAsync(h->d_Fp.p, homography, sizeof(float) * 9 * n_pairs, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pose_homography, dim3(n_pairs), dim3(64), 0, s, h->d_Fp.p, h->d_K.p, h->d_ppts.p,
+                       h->d_pref.p, h->d_pstart.p, h->d_cand.p, h->d_good.p);
+    ORBX_HIP(hipGetLastError());
+    std::vector<double> sol((size_t)n_pairs * 60);
+    std::vector<int32_t> info((size_t)n_pairs * 2);
+    ORBX_HIP(hipMemcpyAsync(sol.data(), h->d_cand.p, sizeof(double) * sol.size(), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipMemcpyAsync(info.data(), h->d_good.p, sizeof(int32_t) * info.size(), hipMemcpyDeviceToHost, s));
+    ORBX_HIP(hipStreamSynchronize(s));
+    for (int p = 0; p < n_pairs; p++) {
+        // `if (!sols.empty()) idx = sols.at<int>(0, 0)`: the lowest visible solution
+        const int mask = info[2 * p + 1];
+        const int idx = mask ? __builtin_ctz((unsigned)mask) : -1;
+        solution[p] = idx;
+        for (int i = 0; i < 9; i++) rotation[(size_t)p * 9 + i] = idx >= 0 ? sol[(size_t)p * 60 + idx * 15 + i] : 0.0;
+        for (int i = 0; i < 3; i++)
+            translation[(size_t)p * 3 + i] = idx >= 0 ? sol[(size_t)p * 60 + idx * 15 + 9 + i] : 0.0;
+        if (n_solutions) n_solutions[p] = info[2 * p];
+    }
+    if (all_solutions) std::memcpy(all_solutions, sol.data(), sizeof(double) * sol.size());
+    return ORBX_OK;
+}
+
 }  // extern "C"

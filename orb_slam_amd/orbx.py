@@ -27,7 +27,7 @@ SYMBOLS = [
     "orbx_match_projection_frame", "orbx_match_projection_points", "orbx_ransac_create", "orbx_ransac_destroy",
     "orbx_ransac_fh", "orbx_ransac_fh_batch", "orbx_ransac_fh_batch_static", "orbx_ransac_fh_all", "orbx_ransac_make_sets",
     "orbx_ransac_last_timings", "orbx_extractor_set_frame_model", "orbx_undistort_points",
-    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_match_bow_batch", "orbx_match_epipolar_batch", "orbx_recover_pose_batch", "orbx_triangulate_batch",
+    "orbx_extractor_device_grid", "orbx_match_projection_frame_batch", "orbx_selftest_retain_best", "orbx_selftest_retain_best_device", "orbx_match_bow", "orbx_best_descriptor_batch", "orbx_match_epipolar", "orbx_fuse_search", "orbx_match_bow_batch", "orbx_match_epipolar_batch", "orbx_recover_pose_batch", "orbx_recover_pose_homography_batch", "orbx_triangulate_batch",
     "orbx_sequence_open", "orbx_sequence_close", "orbx_sequence_length", "orbx_sequence_entry", "orbx_png_decode",
     "orbx_png_read", "orbx_depth_to_float", "orbx_feeder_create", "orbx_feeder_destroy", "orbx_feeder_start_sequence",
     "orbx_feeder_start_memory", "orbx_feeder_next",
@@ -665,6 +665,27 @@ class Ransac:
         _check(lib().orbx_recover_pose_batch(self._h, P, _p(F), _p(K), _p(pts), _p(ref), _p(ps), _p(R), _p(t),
                                              _p(good)), "orbx_recover_pose_batch")
         return R[:P], t[:P], good[:P]
+
+    def recover_pose_homography_batch(self, H, K, pts, ref, pair_start):
+        """Initializer::findRtWithHomography with the visibility filter's points as floats.  Returns (R, t, index of
+        the chosen motion or -1, all motions [pairs, 4, 15] as (R 9, t 3, n 3), number of motions 1 | 4)."""
+        H = np.ascontiguousarray(H, np.float32).reshape(-1, 9)
+        K = np.ascontiguousarray(K, np.float32).reshape(9)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+        ref = np.ascontiguousarray(ref, np.float64).reshape(-1, 2)
+        ps = np.ascontiguousarray(pair_start, np.int32)
+        P = len(ps) - 1
+        if len(H) != P or len(pts) != len(ref) or (P >= 0 and len(pts) != (ps[-1] if len(ps) else 0)):
+            raise ValueError("recover_pose_homography_batch: shapes do not agree")
+        R = np.zeros((max(P, 1), 3, 3), np.float64)
+        t = np.zeros((max(P, 1), 3), np.float64)
+        idx = np.zeros(max(P, 1), np.int32)
+        sols = np.zeros((max(P, 1), 4, 15), np.float64)
+        nsol = np.zeros(max(P, 1), np.int32)
+        _check(lib().orbx_recover_pose_homography_batch(self._h, P, _p(H), _p(K), _p(pts), _p(ref), _p(ps), _p(R),
+                                                        _p(t), _p(idx), _p(sols), _p(nsol)),
+               "orbx_recover_pose_homography_batch")
+        return R[:P], t[:P], idx[:P], sols[:P], nsol[:P]
 
     def triangulate_batch(self, K, R, t, pts, ref, pair_start):
         K = np.ascontiguousarray(K, np.float32).reshape(9)

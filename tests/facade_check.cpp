@@ -350,6 +350,19 @@ int main(int argc, char** argv) {
         init3.findFundamentalAndHomography();
         cv::Mat F2 = init2.getFundamentalMat(), F3 = init3.getFundamentalMat();
         std::printf("seam_same_F=%d\n", (int)(!F2.empty() && !F3.empty() && std::memcmp(F2.data, F3.data, 36) == 0));
+        // the homography branch: refused as in the reference unless the additive switch is set
+        cv::Mat Rh, th;
+        const bool h_default = init3.findRtWithHomography(ip, ir, Rh, th);
+        const bool untouched = Rh.empty() && th.empty();
+        init3.setHomographyDecomposition(true);
+        const bool h_switch = init3.findRtWithHomography(ip, ir, Rh, th);
+        double det = 1.0;
+        if (!Rh.empty()) {
+            const double* r = Rh.ptr<double>();
+            det = r[0] * (r[4] * r[8] - r[5] * r[7]) - r[1] * (r[3] * r[8] - r[5] * r[6]) + r[2] * (r[3] * r[7] - r[4] * r[6]);
+        }
+        std::printf("h_default=%d untouched=%d h_switch=%d h_shape_ok=%d h_det_ok=%d\n", (int)h_default, (int)untouched,
+                    (int)h_switch, (int)(Rh.empty() == th.empty()), (int)(std::fabs(det - 1.0) < 1e-9));
     }
     return 0;
 }

@@ -116,3 +116,5 @@ def test_facade_runs_on_gpu(tmp_path):
     assert abs(float(pose.split("r00=")[1].split()[0]) - 0.9988) < 2e-3   # cos(0.05)
     assert float(pose.split("tx=")[1].split()[0]) > 0.9                   # t = (0.3, 0.02, 0.05) normalised
     assert "two_threads_same=1" in out and "seam_same_F=1" in out
+    # the homography branch fails as the reference's does until the additive switch is set
+    assert "h_default=0 untouched=1 h_switch=1 h_shape_ok=1 h_det_ok=1" in out

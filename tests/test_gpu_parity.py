@@ -1461,6 +1461,88 @@ def test_pose_recovery_and_triangulation_bit_exact(oracle, ransac):
     assert np.isfinite(q).all()
 
 
+def _planar_pair(rng, K, n, rectified):
+    """A plane seen from two poses: the homography in pixels (float32, arbitrary scale), the true motion, and n
+    correspondences - rectified (K^-1 x, what the visibility filter is specified for) or in pixels (what the
+    reference passes)."""
+    Kd = K.astype(np.float64)
+    a, b = rng.uniform(-0.2, 0.2, 2)
+    Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    R = Ry @ Rx
+    t = rng.normal(size=3) * 0.3
+    nrm = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 1.0])
+    nrm /= np.linalg.norm(nrm)
+    d = rng.uniform(2, 5)
+    Hn = R + np.outer(t, nrm) / d
+    H = Kd @ Hn @ np.linalg.inv(Kd)
+    H = (H / H[2, 2] * rng.uniform(0.3, 3)).astype(np.float32)
+    X = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), np.zeros(n)], 1)
+    X[:, 2] = (d - X[:, :2] @ nrm[:2]) / nrm[2]
+    X2 = (R @ X.T).T + t
+    x1, x2 = X / X[:, 2:], X2 / X2[:, 2:]
+    if not rectified:
+        x1, x2 = (Kd @ x1.T).T, (Kd @ x2.T).T
+    f32 = lambda v: v[:, :2].astype(np.float32).astype(np.float64)
+    return H, R, t / d, nrm, f32(x1), f32(x2)
+
+
+def test_homography_pose_recovery_bit_exact(oracle, ransac):
+    """Initializer::findRtWithHomography (Initializer.cpp:112-163) as its statements read - cv::decomposeHomographyMat,
+    cv::filterHomographyDecompByVisibleRefpoints, first solution kept - for a batch of pairs: every motion, the
+    number of motions, the solution chosen and its R, t equal the oracle's doubles bit for bit.  Covers rectified
+    points (the filter's contract; the true motion must be among the visible ones), pixel points (what the
+    reference passes), pure rotations (one motion), arbitrary 3 x 3 matrices, a zero matrix and pairs without points."""
+    rng = np.random.default_rng(211)
+    K = np.array([[517.3, 0, 318.6], [0, 516.5, 255.3], [0, 0, 1]], np.float32)
+    sizes = [0, 1, 5, 63, 64, 65, 128, 700, 2000] + rng.integers(8, 400, 30).tolist()
+    Hs, pts_l, ref_l, truth = [], [], [], []
+    for p, n in enumerate(sizes):
+        rectified = p % 2 == 0
+        H, R, t, nrm, before, after = _planar_pair(rng, K, n, rectified)
+        kind = "plane"
+        if p % 9 == 4:
+            a = rng.uniform(-0.2, 0.2)
+            Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+            Kd = K.astype(np.float64)
+            H = (Kd @ Rz @ np.linalg.inv(Kd) * 1.7).astype(np.float32)
+            kind = "rotation"
+        elif p % 9 == 6:
+            H = rng.normal(size=(3, 3)).astype(np.float32)
+            kind = "random"
+        elif p % 13 == 8:
+            H = np.zeros((3, 3), np.float32)
+            kind = "zero"
+        Hs.append(H)
+        pts_l.append(before)
+        ref_l.append(after)
+        truth.append((kind, rectified, R, t, nrm))
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    R, t, idx, sols, nsol = ransac.recover_pose_homography_batch(
+        np.stack(Hs), K, np.concatenate(pts_l), np.concatenate(ref_l), start)
+    n_true = n_planes = 0
+    for p, n in enumerate(sizes):
+        oR, ot, on = oracle.decompose_homography(Hs[p], K)
+        assert nsol[p] == len(oR), p
+        got = sols[p, :nsol[p]]
+        assert np.array_equal(got[:, :9].reshape(-1, 3, 3), oR, equal_nan=True), p
+        assert np.array_equal(got[:, 9:12], ot, equal_nan=True) and np.array_equal(got[:, 12:], on, equal_nan=True), p
+        keep = oracle.filter_homography_visible(oR, on, pts_l[p], ref_l[p])
+        fR, ft, fi = oracle.recover_pose_homography(Hs[p], K, pts_l[p], ref_l[p])
+        assert fi == (keep[0] if len(keep) else -1) == idx[p], p
+        if fi >= 0:
+            assert np.array_equal(R[p], fR, equal_nan=True) and np.array_equal(t[p], ft, equal_nan=True), p
+        else:
+            assert not R[p].any() and not t[p].any()
+        kind, rectified, Rg, tg, ng = truth[p]
+        if kind == "rotation":
+            assert nsol[p] == 1
+        if kind == "plane" and rectified and n >= 5:
+            n_planes += 1
+            n_true += any(np.abs(oR[k] - Rg).max() < 1e-5 and np.abs(on[k] - ng).max() < 1e-4 for k in keep)
+    assert n_planes > 5 and n_true == n_planes
+
+
 def test_backend_matchers_batched_equal_oracle(oracle, matcher, ex1000, test_images):
     """orbx_match_bow_batch / orbx_match_epipolar_batch: key-frame pairs of different sizes side by side, each
     equal to the oracle's result for that pair (and so to the single-pair entry points)."""

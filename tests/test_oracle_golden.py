@@ -230,3 +230,56 @@ def test_ransac_oracle_recovers_planted_model(oracle):
     assert r["best_it"][1] >= 0 and r["inliers_h"].sum() > 250
     assert np.abs(r["H"] / r["H"][2, 2] - Ht).max() < 0.5
     assert r["score_h"] > r["score_f"] * 0.5
+
+
+def test_pose_oracle_recovers_planted_motions(oracle):
+    """The pose oracles have no fixture in the reference (parity unpinned), so they are held to what their
+    algorithms promise.  Homography branch: every motion of cv::decomposeHomographyMat reproduces the normalised
+    homography as R + t n^T with a proper rotation, the planted motion is among the four, and the visibility
+    filter keeps it for rectified points.  Fundamental branch: the planted rotation and the direction of the
+    planted translation come back from noise-free correspondences."""
+    rng = np.random.default_rng(5)
+    K = np.array([[520, 0, 320], [0, 525, 240], [0, 0, 1]], np.float32)
+    Kd = K.astype(np.float64)
+    for trial in range(20):
+        a, b = rng.uniform(-0.2, 0.2, 2)
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        Rg = Ry @ Rx
+        tg = rng.normal(size=3)
+        tg *= rng.uniform(0.3, 0.6) / np.linalg.norm(tg)   # depth / baseline stays under recoverPose's limit of 50
+        ng = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 1.0])
+        ng /= np.linalg.norm(ng)
+        d = rng.uniform(2, 5)
+        Hn = Rg + np.outer(tg, ng) / d
+        H = Kd @ Hn @ np.linalg.inv(Kd)
+        H = (H / H[2, 2] * rng.uniform(0.3, 3)).astype(np.float32)
+        R, t, nrm = oracle.decompose_homography(H, K)
+        assert len(R) == 4
+        Hn_f32 = np.linalg.inv(Kd) @ H.astype(np.float64) @ Kd
+        Hn_f32 /= np.linalg.svd(Hn_f32, compute_uv=False)[1]
+        for k in range(4):
+            assert np.allclose(R[k] @ R[k].T, np.eye(3), atol=1e-9) and abs(np.linalg.det(R[k]) - 1) < 1e-9
+            assert np.allclose(R[k] + np.outer(t[k], nrm[k]), Hn_f32, atol=1e-9)
+        hit = [k for k in range(4) if np.abs(R[k] - Rg).max() < 1e-5 and np.abs(nrm[k] - ng).max() < 1e-4]
+        assert len(hit) == 1 and np.allclose(t[hit[0]], tg / d, atol=1e-4)
+        X = np.stack([rng.uniform(-1, 1, 50), rng.uniform(-1, 1, 50), np.zeros(50)], 1)
+        X[:, 2] = (d - X[:, :2] @ ng[:2]) / ng[2]
+        X2 = (Rg @ X.T).T + tg
+        x1, x2 = X / X[:, 2:], X2 / X2[:, 2:]
+        keep = oracle.filter_homography_visible(R, nrm, x1[:, :2], x2[:, :2])
+        assert hit[0] in keep and len(keep) <= 2
+        # fundamental branch on a general scene with the same motion
+        Y = np.stack([rng.uniform(-2, 2, 60), rng.uniform(-1.5, 1.5, 60), rng.uniform(2, 7, 60)], 1)
+        y1 = (Kd @ Y.T).T
+        y2 = (Kd @ (Rg @ Y.T + tg[:, None])).T
+        tx = np.array([[0, -tg[2], tg[1]], [tg[2], 0, -tg[0]], [-tg[1], tg[0], 0]])
+        F = np.linalg.inv(Kd).T @ tx @ Rg @ np.linalg.inv(Kd)
+        F = (F / np.linalg.norm(F)).astype(np.float32)
+        fR, ft, good = oracle.recover_pose_fundamental(F, K, y2[:, :2] / y2[:, 2:], y1[:, :2] / y1[:, 2:])
+        assert good >= 55 and np.abs(fR - Rg).max() < 1e-2
+        assert np.dot(ft, tg) / np.linalg.norm(tg) > 0.99
+    # a pure rotation has one motion and no plane
+    R, t, nrm = oracle.decompose_homography(np.eye(3, dtype=np.float32) * 2.5, K)
+    assert len(R) == 1 and np.allclose(R[0], np.eye(3), atol=1e-12) and not t.any() and not nrm.any()
+
