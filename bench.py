@@ -162,7 +162,10 @@ def main():
     ap.add_argument("--pyramid-kernel", type=int, default=0,
                     help="0 / 1: level by level (the default), 2: the one-pass kernel")
     ap.add_argument("--pyramid-rows", type=int, default=0, help="image rows per step of the one-pass pyramid kernel")
-    ap.add_argument("--profile-round", default="r02", help="prefix of the PMC summaries under profiles/ to quote")
+    ap.add_argument("--pyramid-tail", type=int, default=0,
+                    help="levels above this one in one launch (orbx_extractor_set_pyramid_tail; 0 = level by level)")
+    ap.add_argument("--pyramid-tail-rows", type=int, default=0)
+    ap.add_argument("--profile-round", default="r03", help="prefix of the PMC summaries under profiles/ to quote")
     args = ap.parse_args()
 
     import torch
@@ -225,6 +228,8 @@ def main():
             self.ex.set_blur_fork(max(1, args.streams) == 1)
             if args.pyramid_kernel or args.pyramid_rows:
                 self.ex.set_pyramid_kernel(args.pyramid_kernel, args.pyramid_rows)
+            if args.pyramid_tail:
+                self.ex.set_pyramid_tail(args.pyramid_tail, args.pyramid_tail_rows)
             self.mt = orbx.Matcher(device=local_rank)
             self.mt.set_stream(self.tstream.cuda_stream)
             self.sf = self.ex.scale_tables()[1]

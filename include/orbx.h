@@ -124,6 +124,14 @@ orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled);
    one-pass kernel converts (default 8).  Results are identical. */
 orbx_status orbx_extractor_set_pyramid_kernel(orbx_extractor* h, int kind, int rows_per_step);
 
+/* No counterpart in the reference: the small levels of the pyramid in one launch.  Levels 1 .. base_level are resized
+   level by level (each spread over the whole chip); the levels above base_level, which are too small to fill the
+   chip one at a time, are then produced by ONE launch in which a workgroup per frame reads level base_level's rows
+   once and walks the remaining levels through LDS rings.  base_level 0 turns this off.  rows_per_step: rows of
+   level base_level a step takes (0 keeps the current value, default 16).  A geometry the kernel does not suit is
+   built level by level throughout.  Results are identical either way. */
+orbx_status orbx_extractor_set_pyramid_tail(orbx_extractor* h, int base_level, int rows_per_step);
+
 /* Camera model of Camera::undistortPoints (src/geometry/camera.cpp:97-126 -> cv::undistortPoints with P = K).
    Intrinsics and distortion as the reference holds them (cv::Mat_<float> widened to double). */
 typedef struct { double fx, fy, cx, cy, k1, k2, p1, p2, k3; } orbx_camera;
@@ -478,10 +486,11 @@ orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int 
    (which rows every level emits in which step, the depth of every LDS ring), checks the plan against its rings, and
    - with image and atlas non-NULL - executes the same tables on the CPU.  info[4] = steps, LDS bytes, atlas width,
    atlas height.  ORBX_UNSUPPORTED when the geometry does not suit that kernel (the extractor then builds the pyramid
-   level by level). */
+   level by level).  base_level > 0 plans the tail form (orbx_extractor_set_pyramid_tail): the atlas passed in must
+   already hold pyramid level base_level, the levels above it are computed from there (image may then be NULL). */
 orbx_status orbx_selftest_stream_pyramid(const orbx_extractor_params* params, const uint8_t* image, int width,
                                          int height, int stride, int channels, int rows_per_step, size_t max_lds_bytes,
-                                         uint8_t* atlas, size_t atlas_capacity, int32_t* info);
+                                         int base_level, uint8_t* atlas, size_t atlas_capacity, int32_t* info);
 
 /* Measurement hook (no counterpart in the reference): the vector issue rate this GPU sustains right now, in
    wave-instructions per second over the whole chip, for one instruction mix: kind 0 = v_add_u32, 1 = v_xor_b32 +

@@ -399,6 +399,9 @@ __device__ __forceinline__ uint2 hfilter_q8(unsigned d0, unsigned d1, unsigned d
 // few threads and handed over through a small LDS cache; the image bytes level 0 converts in step s + 1 are loaded
 // into registers at the top of step s.  What is left on the critical path of a step is LDS and arithmetic.
 // (four wavefronts per SIMD = four frames per CU: with 792 frames on 256 CUs every frame must be resident at once)
+// TAIL: plan level 0 is a pyramid level an earlier kernel has already written: `img` then points at that level's
+// interior in the atlas (one channel, stride = atlas width, frame_stride = atlas bytes); its rows only enter the ring.
+template <bool TAIL>
 __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pyramid_stream(const uint8_t* __restrict__ img, size_t frame_stride,
                                                                    int stride, int ch, uint8_t* __restrict__ atlas,
                                                                    size_t atlas_bytes, StreamParams P,
@@ -527,8 +530,10 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
                     out.z = gray4(v1.z, v1.w, v2.x);
                     out.w = gray4(v2.y, v2.z, v2.w);
                 }
-                __builtin_memcpy(plane + (size_t)(L0.ay + y) * aw + ax, &out, 16);
-                if (r.mirror >= 0) __builtin_memcpy(plane + (size_t)r.mirror * aw + ax, &out, 16);
+                if (!TAIL) {
+                    __builtin_memcpy(plane + (size_t)(L0.ay + y) * aw + ax, &out, 16);
+                    if (r.mirror >= 0) __builtin_memcpy(plane + (size_t)r.mirror * aw + ax, &out, 16);
+                }
                 if (L0.depth > 0)
                     *(uint4*)(s_ring + L0.lds_off + __umul24((r.slots >> 16) & 255u, (unsigned)L0.pitch) + 4 * q) = out;
             }
@@ -539,8 +544,10 @@ __global__ __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(
                 if (ax >= x_first && ax < x_last) {
                     const StreamRow r = rcache[ry];
                     const uint8_t v = (uint8_t)(ch == 1 ? gr.e : gray_of(gr.e & 255u, (gr.e >> 8) & 255u, (gr.e >> 16) & 255u));
-                    plane[(size_t)(L0.ay + y) * aw + ax] = v;
-                    if (r.mirror >= 0) plane[(size_t)r.mirror * aw + ax] = v;
+                    if (!TAIL) {
+                        plane[(size_t)(L0.ay + y) * aw + ax] = v;
+                        if (r.mirror >= 0) plane[(size_t)r.mirror * aw + ax] = v;
+                    }
                     if (L0.depth > 0)
                         ((uint8_t*)(s_ring + L0.lds_off + __umul24((r.slots >> 16) & 255u, (unsigned)L0.pitch)))[ax - L0.ax_begin] = v;
                 }

@@ -163,22 +163,27 @@ orbx_status orbx_selftest_retain_best(const float* keys, int n, int n_points, in
 
 orbx_status orbx_selftest_stream_pyramid(const orbx_extractor_params* params, const uint8_t* image, int width,
                                          int height, int stride, int channels, int rows_per_step, size_t max_lds_bytes,
-                                         uint8_t* atlas, size_t atlas_capacity, int32_t* info) {
+                                         int base_level, uint8_t* atlas, size_t atlas_capacity, int32_t* info) {
     if (!params || !info || width <= 0 || height <= 0 || (channels != 1 && channels != 3)) return ORBX_BAD_ARG;
     orbx::HostGeometry hg;
     orbx_status st = orbx::compute_geometry(*params, width, height, params->level_pyramid, hg);
     if (st != ORBX_OK) return st;
+    if (base_level < 0 || base_level >= hg.g.nlevels) return ORBX_BAD_ARG;
     orbx::StreamPlan sp;
     info[2] = hg.g.atlas_w;
     info[3] = hg.g.atlas_h;
-    if (!orbx::build_stream_plan(hg, width, height, rows_per_step, max_lds_bytes, sp)) return ORBX_UNSUPPORTED;
+    const orbx::LevelInfo& base = hg.g.L[base_level];
+    if (!orbx::build_stream_plan(hg, base.w, base.h, rows_per_step, max_lds_bytes, sp, base_level)) return ORBX_UNSUPPORTED;
     info[0] = sp.prm.n_steps;
     info[1] = (int32_t)sp.lds_bytes;
-    if (!image || !atlas) return ORBX_OK;
-    if (atlas_capacity < hg.atlas_bytes || stride < width * channels) return ORBX_CAPACITY;
+    if (!atlas || (base_level == 0 && !image)) return ORBX_OK;
+    if (atlas_capacity < hg.atlas_bytes || (base_level == 0 && stride < width * channels)) return ORBX_CAPACITY;
     // an access outside the atlas or the rings would be a fault on the device: report it as such
-    if (!orbx::emulate_stream_pyramid(sp, image, stride, channels, atlas, hg.g.atlas_h)) return ORBX_DEVICE;
-    return ORBX_OK;
+    const bool inside = base_level == 0
+        ? orbx::emulate_stream_pyramid(sp, image, stride, channels, atlas, hg.g.atlas_h)
+        : orbx::emulate_stream_pyramid(sp, atlas + (size_t)base.y * hg.g.atlas_w + base.x, hg.g.atlas_w, 1, atlas,
+                                       hg.g.atlas_h, true);
+    return inside ? ORBX_OK : ORBX_DEVICE;
 }
 
 orbx_status orbx_undistort_points(const orbx_camera* camera, const float* xy_in, int n, float* xy_out) {

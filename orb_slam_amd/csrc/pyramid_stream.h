@@ -147,12 +147,25 @@ inline bool verify_stream_plan(const StreamPlan& sp) {
 // Builds the plan for one geometry.  rows_per_step: level-0 rows a step converts.  Returns false (sp.ok stays false)
 // when the geometry does not suit the streaming form: a level lower than twice the border, a resize whose four-pixel
 // source span exceeds two dwords, rings beyond max_lds bytes.
-inline bool build_stream_plan(const HostGeometry& hg, int w, int hgt, int rows_per_step, size_t max_lds, StreamPlan& sp) {
+//
+// base > 0 plans the TAIL of the pyramid only: plan level 0 is pyramid level `base`, which an earlier kernel has
+// already written to the atlas; the pass reads its interior rows from there (as a one-channel image of that size),
+// keeps them in the ring and emits the levels above it.  w, hgt are then the size of that level.
+inline bool build_stream_plan(const HostGeometry& hg, int w, int hgt, int rows_per_step, size_t max_lds, StreamPlan& sp,
+                              int base = 0) {
     using namespace streamdetail;
     sp = StreamPlan();
-    const Geom& g = hg.g;
-    const int nl = g.nlevels, B = g.border;
+    const int B = hg.g.border;
+    if (base < 0 || base >= hg.g.nlevels) return false;
+    const int nl = hg.g.nlevels - base;
+    // the plan's own numbering: level l of the plan is pyramid level base + l
+    struct GeomView {
+        const LevelInfo* L;
+        int atlas_w;
+    } g{hg.g.L + base, hg.g.atlas_w};
+    const ResizePlan* rplan = hg.rplan + base;
     if (nl < 1 || rows_per_step < 1 || g.L[0].w != w || g.L[0].h != hgt) return false;
+    if (base > 0 && nl < 2) return false;
     for (int l = 0; l < nl; l++)
         if (g.L[l].h < 2 * B + 2 || g.L[l].w < 8) return false;
     StreamParams& P = sp.prm;
@@ -166,11 +179,22 @@ inline bool build_stream_plan(const HostGeometry& hg, int w, int hgt, int rows_p
         const int ax_begin = (rx - B) & ~15;
         const int x_last = rx + w + B;
         P.nq = (x_last - ax_begin + 15) >> 4;
-        P.q_in0 = (rx - ax_begin + 15) >> 4;
-        P.q_in1 = (rx + w - ax_begin) >> 4;
-        P.n_in = std::max(P.q_in1 - P.q_in0, 0);
-        P.n_edge = (P.nq - P.n_in) * 16;
-        P.left_edge = P.q_in0 * 16;
+        if (base == 0) {
+            P.q_in0 = (rx - ax_begin + 15) >> 4;
+            P.q_in1 = (rx + w - ax_begin) >> 4;
+            P.n_in = std::max(P.q_in1 - P.q_in0, 0);
+            P.n_edge = (P.nq - P.n_in) * 16;
+            P.left_edge = P.q_in0 * 16;
+        } else {
+            // the tail form loads whole groups from the atlas, border bytes included: every group that holds an
+            // interior pixel (the levels above sample interior pixels only), no single pixels
+            P.q_in0 = (rx - ax_begin) >> 4;
+            P.q_in1 = (rx + w - ax_begin + 15) >> 4;
+            P.n_in = P.q_in1 - P.q_in0;
+            P.n_edge = 0;
+            P.left_edge = 0;
+            if (ax_begin < 0 || ax_begin + 16 * P.q_in1 > g.atlas_w) return false;
+        }
         P.magic_in = magic_for(P.n_in);
         P.magic_edge = magic_for(P.n_edge);
         if (P.n_in == 0) return false;
@@ -186,7 +210,7 @@ inline bool build_stream_plan(const HostGeometry& hg, int w, int hgt, int rows_p
     for (int l = 1; l < nl; l++) {
         const LevelInfo& D = g.L[l];
         const LevelInfo& S = g.L[l - 1];
-        const ResizePlan& rp = hg.rplan[l];
+        const ResizePlan& rp = rplan[l];
         StreamLevel& L = P.L[l];
         L.w = D.w; L.h = D.h; L.ax = D.x; L.ay = D.y;
         L.ax_begin = rp.ax_begin;
@@ -326,8 +350,10 @@ inline bool build_stream_plan(const HostGeometry& hg, int w, int hgt, int rows_p
 // The plan executed on the CPU: the same tables, the same order of steps, scalar arithmetic.  image: 8-bit, 1 or 3
 // channels (BGR); atlas: atlas_w x atlas_h bytes, only the levels' padded rectangles are written.
 // Returns false if any access the tables lead to leaves the atlas (atlas_h rows) or the rings.
+// tail: the plan starts at a level that is already in the atlas (image = that level's interior, ch = 1, stride =
+// atlas width): its rows are only loaded into the ring, not written again.
 inline bool emulate_stream_pyramid(const StreamPlan& sp, const uint8_t* image, int stride, int ch, uint8_t* atlas,
-                                   int atlas_h) {
+                                   int atlas_h, bool tail = false) {
     const StreamParams& P = sp.prm;
     const int nl = P.nlevels, aw = P.aw, B = P.border;
     std::vector<unsigned> lds((size_t)sp.prm.ring_dwords, 0xdeadbeefu);
@@ -348,18 +374,28 @@ inline bool emulate_stream_pyramid(const StreamPlan& sp, const uint8_t* image, i
             const StreamLevel& L = P.L[0];
             for (int y = sp.sched[(size_t)(s * nl) * 2]; y < sp.sched[(size_t)(s * nl) * 2 + 1]; y++) {
                 const StreamRow& r = sp.rows[L.row_off + y];
+                auto ring_put = [&](int ax, uint8_t v) {
+                    const size_t byte = ((size_t)L.lds_off + (size_t)((r.slots >> 16) & 255) * L.pitch) * 4 + (ax - L.ax_begin);
+                    if (ax < L.ax_begin || (byte >> 2) >= next.size()) { inside = false; return; }
+                    unsigned& word = next[byte >> 2];
+                    word = (word & ~(0xffu << (8 * (byte & 3)))) | ((unsigned)v << (8 * (byte & 3)));
+                };
+                if (tail) {
+                    // whole 16-byte groups of the level's row as the atlas holds it
+                    for (int ax = L.ax_begin + 16 * P.q_in0; ax < L.ax_begin + 16 * P.q_in1; ax++) {
+                        const int row = L.ay + y;
+                        if (row < 0 || row >= atlas_h || ax < 0 || ax >= aw) { inside = false; continue; }
+                        if (L.depth > 0) ring_put(ax, atlas[(size_t)row * aw + ax]);
+                    }
+                    continue;
+                }
                 const uint8_t* src = image + (size_t)y * stride;
                 for (int ax = L.ax - B; ax < L.ax + L.w + B; ax++) {
                     const uint8_t* px = src + (size_t)reflect(ax - L.ax, L.w) * ch;
                     const uint8_t v = (uint8_t)(ch == 1 ? px[0] : gray(px[0], px[1], px[2]));
                     put(L.ay + y, ax, v);
                     if (r.mirror >= 0) put(r.mirror, ax, v);
-                    if (L.depth > 0) {
-                        const size_t byte = ((size_t)L.lds_off + (size_t)((r.slots >> 16) & 255) * L.pitch) * 4 + (ax - L.ax_begin);
-                        if (ax < L.ax_begin || (byte >> 2) >= next.size()) { inside = false; continue; }
-                        unsigned& word = next[byte >> 2];
-                        word = (word & ~(0xffu << (8 * (byte & 3)))) | ((unsigned)v << (8 * (byte & 3)));
-                    }
+                    if (L.depth > 0) ring_put(ax, v);
                 }
             }
         }

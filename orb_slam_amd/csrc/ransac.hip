@@ -97,7 +97,6 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
     hipLaunchKernelGGL(k_solve_h, dim3(hyp_blocks64), dim3(64), 0, sh, w.pn, w.rn, n, w.T, d_sets8,
                        iterations, pairs, w.Hall, w.Hiall);
     T.end(RT_SOLVE_H, sh);
-    T.begin(RT_SCORE_H, sh);
     T.begin(RT_SCORE_F, s);
     if (flat)
         hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, w.pd, n, w.Fall, iterations, pairs, sigma,
@@ -107,6 +106,7 @@ orbx_status run_batch(orbx_ransac* h, const Workspace& w, const float* d_points,
             hipLaunchKernelGGL(k_score_f, dim3(score_blocks), dim3(256), 0, s, w.pd + (size_t)p * n * 4, n,
                                w.Fall + (size_t)p * iterations * 9, iterations, 1, sigma, w.sf + (size_t)p * iterations);
     T.end(RT_SCORE_F, s);
+    T.begin(RT_SCORE_H, sh);
     if (flat)
         hipLaunchKernelGGL(k_score_h, dim3(score_blocks), dim3(256), 0, sh, d_points, d_ref, n, w.Hall,
                            w.Hiall, iterations, pairs, sigma, w.sh);

@@ -34,7 +34,7 @@ SYMBOLS = [
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
     "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream", "orbx_matcher_set_hamming_kernel",
     "orbx_normalize_points", "orbx_fundamental_npt", "orbx_homography_dlt", "orbx_ransac_set_fork",
-    "orbx_selftest_stream_pyramid", "orbx_extractor_set_pyramid_kernel",
+    "orbx_selftest_stream_pyramid", "orbx_extractor_set_pyramid_kernel", "orbx_extractor_set_pyramid_tail",
 ]
 
 
@@ -232,6 +232,11 @@ class Extractor:
     def set_blur_fork(self, enabled):
         """Blur of a batch on the handle's side stream (default) or in line (several batches in flight)."""
         _check(lib().orbx_extractor_set_blur_fork(self._h, int(bool(enabled))), "orbx_extractor_set_blur_fork")
+
+    def set_pyramid_tail(self, base_level, rows_per_step=0):
+        """Levels above base_level in one launch (0 = off): see orbx_extractor_set_pyramid_tail."""
+        _check(lib().orbx_extractor_set_pyramid_tail(self._h, base_level, rows_per_step),
+               "orbx_extractor_set_pyramid_tail")
 
     def set_pyramid_kernel(self, kind, rows_per_step=0):
         """0 / 1: level by level, 2: the one-pass kernel whenever the geometry allows."""
@@ -593,24 +598,32 @@ def selftest_retain_best_device(keys, n_points, device=0):
     return perm[:n.value].copy()
 
 
-def selftest_stream_pyramid(params, image, rows_per_step=8, max_lds_bytes=65536, width=None, height=None):
+def selftest_stream_pyramid(params, image, rows_per_step=8, max_lds_bytes=65536, width=None, height=None,
+                            base_level=0, atlas=None):
     """Plan of the one-pass pyramid kernel for an image size and, with an image, the plan executed on the CPU.
+    base_level > 0: the tail form; `atlas` must then hold pyramid level base_level already (width, height give the
+    image size) and the levels above it are computed into it.
     Returns (info dict, atlas or None); raises OrbxError(UNSUPPORTED) when the geometry does not suit the kernel."""
     info = np.zeros(4, np.int32)
-    if image is None:
+    if base_level > 0 and atlas is not None:
+        atlas = np.ascontiguousarray(atlas, np.uint8)
         _check(lib().orbx_selftest_stream_pyramid(C.byref(params), None, width, height, width, 1, rows_per_step,
-                                                  C.c_size_t(max_lds_bytes), None, C.c_size_t(0), _p(info)),
+                                                  C.c_size_t(max_lds_bytes), base_level, _p(atlas),
+                                                  C.c_size_t(atlas.size), _p(info)), "orbx_selftest_stream_pyramid")
+    elif image is None:
+        _check(lib().orbx_selftest_stream_pyramid(C.byref(params), None, width, height, width, 1, rows_per_step,
+                                                  C.c_size_t(max_lds_bytes), base_level, None, C.c_size_t(0), _p(info)),
                "orbx_selftest_stream_pyramid")
         atlas = None
     else:
         img, w, h, stride, ch = _img(image)
         _check(lib().orbx_selftest_stream_pyramid(C.byref(params), None, w, h, stride, ch, rows_per_step,
-                                                  C.c_size_t(max_lds_bytes), None, C.c_size_t(0), _p(info)),
+                                                  C.c_size_t(max_lds_bytes), 0, None, C.c_size_t(0), _p(info)),
                "orbx_selftest_stream_pyramid")
         atlas = np.zeros((int(info[3]), int(info[2])), np.uint8)
         _check(lib().orbx_selftest_stream_pyramid(C.byref(params), _p(img), w, h, stride, ch, rows_per_step,
-                                                  C.c_size_t(max_lds_bytes), _p(atlas), C.c_size_t(atlas.size), _p(info)),
-               "orbx_selftest_stream_pyramid")
+                                                  C.c_size_t(max_lds_bytes), 0, _p(atlas), C.c_size_t(atlas.size),
+                                                  _p(info)), "orbx_selftest_stream_pyramid")
     return dict(steps=int(info[0]), lds_bytes=int(info[1]), atlas_w=int(info[2]), atlas_h=int(info[3])), atlas
 
 

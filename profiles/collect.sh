@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the profiles kept in this directory.  Run on the GPU box from the repository root:
-#   bash profiles/collect.sh r02 [quick]
+#   bash profiles/collect.sh r03 [quick]
 # One rocprofv3 run per kind of data (kernel trace; FETCH_SIZE; WRITE_SIZE; two passes of SQ counters): counters
 # are never combined with traces, and every pass has a time limit of its own.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 MODE=${2:-full}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R

@@ -155,6 +155,24 @@ def test_one_pass_pyramid_plan_executes_to_the_oracle_pyramid(oracle):
             assert np.array_equal(atlas[ry - b:ry + rh + b, rx - b:rx + rw + b],
                                   oatlas[ry - b:ry + rh + b, rx - b:rx + rw + b]), (img.shape, nlevels, rows, l)
         assert info["steps"] >= img.shape[0] // rows and 0 < info["lds_bytes"] <= 160 * 1024
+        # the tail form: levels up to `base` taken from the atlas as given, the levels above it computed from there
+        h, w = img.shape[:2]
+        ran = 0
+        for base, trows in ((1, 8), (nlevels // 2, 8), (nlevels // 2, 16), (nlevels - 2, 22)):
+            a = oatlas.copy()
+            for rx, ry, rw, rh in rects[base + 1:]:
+                a[ry - 32:ry + rh + 32, rx - 32:rx + rw + 32] = 0x5a
+            try:
+                tinfo, out = orbx.selftest_stream_pyramid(prm, None, rows_per_step=trows, width=w, height=h,
+                                                          base_level=base, atlas=a, max_lds_bytes=160 * 1024)
+            except orbx.OrbxError as e:
+                assert e.status == orbx.UNSUPPORTED, (img.shape, base, trows)   # too many rows a step for this width
+                continue
+            ran += 1
+            for l, (rx, ry, rw, rh) in enumerate(rects):
+                assert np.array_equal(out[ry - 32:ry + rh + 32, rx - 32:rx + rw + 32],
+                                      oatlas[ry - 32:ry + rh + 32, rx - 32:rx + rw + 32]), (img.shape, base, trows, l)
+        assert ran >= 2, img.shape
     # the VGA / 8-level plan the batch path uses fits several workgroups per CU
     prm = orbx.make_params(n_key_points=1000, level_pyramid=8)
     info, _ = orbx.selftest_stream_pyramid(prm, None, rows_per_step=8, width=640, height=480)

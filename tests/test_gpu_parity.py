@@ -351,6 +351,53 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     ex.close()
 
 
+def test_pyramid_tail_kernel_bit_exact(oracle, test_images):
+    """orbx_extractor_set_pyramid_tail: the levels above a base level in one launch (a workgroup per frame reads the
+    base level from the atlas and walks the rest through LDS rings).  The atlas must equal the oracle's pyramid,
+    padded rectangles included, and the batch extraction the level-by-level result, for every base level, colour and
+    gray, odd sizes; a geometry the kernel does not suit silently stays level by level."""
+    import torch
+    cases = [("vga_color", [test_images[0], test_images[1], synth_image(41, 640, 480, 3)], 8, (1, 2, 3, 4, 5, 6), 8),
+             ("vga_rows16", [test_images[1], synth_image(42, 640, 480)[:, :, None].repeat(3, 2)], 8, (2, 3, 4), 16),
+             ("odd_gray", [synth_image(43, 401, 299), synth_image(44, 401, 299)], 5, (1, 2, 3), 16),
+             ("wide", [synth_image(45, 880, 600, 3)], 6, (1, 3, 4), 8)]
+    for name, frames, nlevels, bases, rows in cases:
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else 3
+        p = oracle.orb_params(nfeatures=1000, nlevels=nlevels)
+        ex = orbx.Extractor(n_key_points=1000, level_pyramid=nlevels, max_width=w, max_height=h, max_batch=len(frames))
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        torch.cuda.synchronize()
+        k1, c1, d1 = ex.extract_batch(dev.data_ptr(), len(frames), w * h * ch, w, h, w * ch, ch, 2000)
+        oatl = [oracle.pyramid(p, img) for img in frames]
+        for base in bases:
+            ex.set_pyramid_tail(base, rows)
+            k2, c2, d2 = ex.extract_batch(dev.data_ptr(), len(frames), w * h * ch, w, h, w * ch, ch, 2000)
+            for f in range(len(frames)):
+                atlas = ex.read_plane(0, w, h, frame=f)
+                oatlas, rects, _ = oatl[f]
+                for l, (rx, ry, rw, rh) in enumerate(rects):
+                    b = 32
+                    assert np.array_equal(atlas[ry - b:ry + rh + b, rx - b:rx + rw + b],
+                                          oatlas[ry - b:ry + rh + b, rx - b:rx + rw + b]), (name, base, f, l)
+                assert c1[f] == c2[f], (name, base, f)
+                assert np.array_equal(k1[f, :c1[f]], k2[f, :c2[f]]) and np.array_equal(d1[f, :c1[f]], d2[f, :c2[f]]), \
+                    (name, base, f)
+        ex.close()
+    # a large batch (more workgroups than CUs) with the setting the bench uses
+    frames = [test_images[i % 2] if i % 5 == 0 else synth_image(500 + i, 640, 480, 3) for i in range(130)]
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(frames))
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    k1, c1, d1 = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1280)
+    ex.set_pyramid_tail(3, 16)
+    k2, c2, d2 = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1280)
+    assert np.array_equal(c1, c2)
+    for f in range(len(frames)):
+        assert np.array_equal(k1[f, :c1[f]], k2[f, :c2[f]]) and np.array_equal(d1[f, :c1[f]], d2[f, :c2[f]]), f
+    ex.close()
+
+
 def test_one_pass_pyramid_kernel_bit_exact(oracle, test_images):
     """The one-pass pyramid kernel (a workgroup per frame, every level from LDS rings, one launch per batch) against
     the oracle's pyramid, padded rectangles included, and the whole batch extraction against the level-by-level
