@@ -30,16 +30,27 @@ public:
         nh_.param<int>(prefix + "wta_k", wta_k_, 2);
         nh_.param<int>(prefix + "patch_size", patch_size_, 31);
         nh_.param<int>(prefix + "score_threshold", score_threshold_, 20);
+        // three additive keys the reference's cfg/orb_extractor.yaml does not have; absent, the extractor is cv::ORB's
+        // (distribution 1: per-cell adaptive FAST threshold + quad-tree distribution, orbx_extractor_set_distribution)
+        nh_.param<int>(prefix + "distribution", distribution_, 0);
+        nh_.param<int>(prefix + "low_score_threshold", low_score_threshold_, 7);
+        nh_.param<int>(prefix + "distribution_cell_size", distribution_cell_size_, 30);
 
         orbx_extractor_params p = {
             n_key_points_, scale_factor_, level_pyramid_, edge_threshold_, first_level_, wta_k_, patch_size_,
             score_threshold_};
         handle_ = orbx_compat::PerThreadHandle<orbx_extractor>(
             // the two sizes are what the handle reserves up front; an image of any other size makes it regrow
-            [p, reserve_width, reserve_height, device]() {
+            [p, reserve_width, reserve_height, device, mode = distribution_, low = low_score_threshold_,
+             cell = distribution_cell_size_]() {
                 orbx_extractor* h = nullptr;
                 orbx_compat::check(
                     orbx_extractor_create(&p, reserve_width, reserve_height, 1, device, &h), "ORBExtractor");
+                if (mode != 0) {
+                    const orbx_status s = orbx_extractor_set_distribution(h, mode, low, cell);
+                    if (s != ORBX_OK) orbx_extractor_destroy(h);
+                    orbx_compat::check(s, "ORBExtractor: distribution");
+                }
                 return h;
             },
             orbx_extractor_destroy);
@@ -130,6 +141,7 @@ private:
     int wta_k_ = 2;
     int patch_size_ = 31;
     int score_threshold_;
+    int distribution_ = 0, low_score_threshold_ = 7, distribution_cell_size_ = 30;
 
     // per-level tables handed out by the getters; filled once from the device-side extractor
     float log_scale_factor_;

@@ -124,6 +124,25 @@ orbx_status orbx_extractor_set_image_cache(orbx_extractor* h, int enabled);
    one-pass kernel converts (default 8).  Results are identical. */
 orbx_status orbx_extractor_set_pyramid_kernel(orbx_extractor* h, int kind, int rows_per_step);
 
+/* No counterpart in the reference (its extractor is cv::ORB: one FAST threshold, retainBest by Harris response,
+   include/orb_slam/geometry/orb_extractor.h:57-80,100-104): an opt-in keypoint distribution, OFF by default so that
+   results equal cv::ORB's.  mode 1:
+     - FAST-9/16 runs at low_threshold; a corner's score is the largest threshold at which it still is a corner;
+     - per-cell adaptive threshold: every level's keypoint area is cut into cells of about cell_size pixels; a cell
+       that holds a corner at the configured score_threshold keeps only such corners, a cell without one keeps every
+       corner at low_threshold;
+     - quad-tree distribution with cv::ORB's per-level quotas: the area starts as round(width / height) boxes (1..8);
+       round by round every box with more than one corner is cut into up to four (at the ceilings of its half width
+       and height; empty quadrants dropped, the others taking the box's place in order); once cutting all of them
+       could pass the quota, boxes are cut largest population first (earlier box first among equals) until the quota
+       is reached; every box keeps its strongest corner (first in raster order among equals), in box order;
+     - keypoint response = the corner score; size, angle, octave, undistortion, grid and descriptors as otherwise.
+   A level keeps at most quota + 2 keypoints, so give orbx_extract_batch a capacity of n_key_points + 3 * levels.
+   The mode lives in the device-resident batch path; orbx_detect runs a batch of one.  A frame with more corners at
+   the low threshold than the candidate list holds (a sixteenth of the pyramid's pixels) is refused with
+   ORBX_UNSUPPORTED.  mode 0 restores cv::ORB's selection. */
+orbx_status orbx_extractor_set_distribution(orbx_extractor* h, int mode, int low_threshold, int cell_size);
+
 /* No counterpart in the reference: the small levels of the pyramid in one launch.  Levels 1 .. base_level are resized
    level by level (each spread over the whole chip); the levels above base_level, which are too small to fill the
    chip one at a time, are then produced by ONE launch in which a workgroup per frame reads level base_level's rows

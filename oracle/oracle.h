@@ -80,6 +80,13 @@ int  orc_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold
 int  orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, int stride, int channels,
                     orc_keypoint* out, int cap);
 /* Per-stage detect: candidates after the FAST-score cull, in the order cv::ORB holds them, with Harris responses. */
+/* Opt-in distribution mode, SELF-ORACLE (the reference has no counterpart; distribute_oracle.cpp states the rule):
+   per-cell adaptive FAST threshold (low_threshold where a cell has no corner at p->fast_threshold) + quad-tree
+   distribution with cv::ORB's per-level quotas.  orc_quadtree_select works on one level's candidate list. */
+int  orc_quadtree_select(const int32_t* xs, const int32_t* ys, const int32_t* scores, int n, int w, int h, int lo,
+                         int quota, int high_threshold, int cell_size, int32_t* kept);
+int  orc_orb_detect_distributed(const orc_orb_params* p, const uint8_t* img, int w, int h, int stride, int channels,
+                                int low_threshold, int cell_size, orc_keypoint* out, int cap);
 int  orc_orb_detect_stage1(const orc_orb_params* p, const uint8_t* img, int w, int h, int stride, int channels,
                            orc_keypoint* out, int cap, int* per_level_counts);
 /* cv::ORB::compute. kps is filtered/reordered in place; returns the new count; desc gets count*32 bytes. */

@@ -675,6 +675,53 @@ int orc_orb_detect(const orc_orb_params* p, const uint8_t* img, int w, int h, in
     return (int)k.size();
 }
 
+/* The opt-in distribution mode (no counterpart in the reference; defined by distribute_oracle.cpp): FAST at the low
+   threshold per level, border rule, per-cell adaptive threshold + quad-tree selection with the level's cv::ORB quota,
+   response = FAST corner score, then orientation and level-0 coordinates as in detect_impl. */
+int orc_orb_detect_distributed(const orc_orb_params* p, const uint8_t* img, int w, int h, int stride, int channels,
+                               int low_threshold, int cell_size, orc_keypoint* out, int cap) {
+    if (w <= 0 || h <= 0) return 0;
+    const int nlevels = p->nlevels;
+    Layout L = make_layout(p, w, h, nlevels);
+    std::vector<uint8_t> gray((size_t)w * h), atlas((size_t)L.atlas_w * L.atlas_h);
+    orc_gray(p, img, w, h, stride, channels, gray.data());
+    build_pyramid(p, L, gray.data(), w, h, atlas.data());
+    std::vector<int> quota;
+    per_level_quota(p, nlevels, quota);
+    std::vector<orc_keypoint> kept_all, kps;
+    const int lo = std::max(3, p->edge_threshold);
+    for (int level = 0; level < nlevels; level++) {
+        const Rect& r = L.rect[level];
+        fast_detect(atlas.data() + (size_t)r.y * L.atlas_w + r.x, r.w, r.h, L.atlas_w, low_threshold, kps);
+        run_by_image_border(kps, r.w, r.h, p->edge_threshold);
+        std::vector<int32_t> xs(kps.size()), ys(kps.size()), sc(kps.size()), kept((size_t)quota[level] + 8);
+        for (size_t i = 0; i < kps.size(); i++) {
+            xs[i] = (int)kps[i].x;
+            ys[i] = (int)kps[i].y;
+            sc[i] = (int)kps[i].response;
+        }
+        const int m = orc_quadtree_select(xs.data(), ys.data(), sc.data(), (int)kps.size(), r.w, r.h, lo, quota[level],
+                                          p->fast_threshold, cell_size, kept.data());
+        for (int j = 0; j < m; j++) {
+            orc_keypoint k = kps[kept[j]];
+            k.octave = level;
+            k.size = p->patch_size * L.scale[level];
+            kept_all.push_back(k);
+        }
+    }
+    std::vector<int> umax;
+    const int half_patch = p->patch_size / 2;
+    make_umax(half_patch, umax);
+    ic_angles(atlas.data(), L.atlas_w, L, kept_all, umax, half_patch);
+    for (auto& k : kept_all) {
+        const float scale = L.scale[k.octave];
+        k.x *= scale;
+        k.y *= scale;
+    }
+    for (size_t i = 0; i < kept_all.size() && (int)i < cap; i++) out[i] = kept_all[i];
+    return (int)kept_all.size();
+}
+
 int orc_orb_detect_stage1(const orc_orb_params* p, const uint8_t* img, int w, int h, int stride, int channels,
                           orc_keypoint* out, int cap, int* per_level_counts) {
     Layout L = make_layout(p, w, h, p->nlevels);

@@ -132,6 +132,27 @@ def detect(p, img, cap=200000):
     return out[:n].copy()
 
 
+def detect_distributed(p, img, low_threshold=7, cell_size=30, cap=200000):
+    """The opt-in distribution mode (self-oracle): per-cell adaptive FAST threshold + quad-tree selection."""
+    img, w, h, stride, ch = _img(img)
+    out = np.zeros(cap, KP_DTYPE)
+    lib().orc_orb_detect_distributed.restype = C.c_int
+    n = lib().orc_orb_detect_distributed(C.byref(p), _p(img), w, h, stride, ch, low_threshold, cell_size, _p(out), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def quadtree_select(xs, ys, scores, w, h, lo, quota, high_threshold, cell_size):
+    xs = np.ascontiguousarray(xs, np.int32)
+    ys = np.ascontiguousarray(ys, np.int32)
+    scores = np.ascontiguousarray(scores, np.int32)
+    kept = np.zeros(quota + 8, np.int32)
+    lib().orc_quadtree_select.restype = C.c_int
+    m = lib().orc_quadtree_select(_p(xs), _p(ys), _p(scores), len(xs), w, h, lo, quota, high_threshold, cell_size,
+                                  _p(kept))
+    return kept[:m].copy()
+
+
 def detect_stage1(p, img, cap=400000):
     img, w, h, stride, ch = _img(img)
     out = np.zeros(cap, KP_DTYPE)

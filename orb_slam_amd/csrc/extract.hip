@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "extract_kernels.h"
+#include "distribute_kernels.h"
 #include "geometry_host.h"
 #include "host_logic.h"
 
@@ -60,6 +61,11 @@ struct orbx_extractor {
     DevBuf<StreamCol> d_tcols;
     DevBuf<StreamRow> d_trows;
     DevBuf<short> d_tsched;
+    // opt-in distribution mode (orbx_extractor_set_distribution): 0 = cv::ORB's own selection
+    int distribute_mode = 0, distribute_low = 7, distribute_cell = 30;
+    DevBuf<uint16_t> d_labels;       // box label per candidate (k_distribute_level's work array)
+    DevBuf<int> d_picked_idx, d_picked_n;
+    int picked_stride = 0;
     int pyramid_kernel = 0;   // 0 / 1: level by level; 2: the one-pass kernel when the plan suits the geometry
     int stream_rows = 8;      // level-0 rows per step of the one-pass kernel
     StreamPlan tplan;         // the tail form: levels above tail_base in one launch
@@ -477,7 +483,8 @@ orbx_status run_detect_stage(orbx_extractor* h, const uint8_t* d_images, int fra
     T.begin(ST_FAST, s);
     ORBX_HIP(hipMemsetAsync(h->d_acc.p, 0, sizeof(int) * h->acc_ints, s));
     hipLaunchKernelGGL(k_fast_nms<false>, dim3(div_up(g.total_tiles, 8) * 8, frames), dim3(256), 0, s, h->d_atlas.p, h->d_score.p,
-                       h->d_mask.p, A, g, h->d_tiles.p, std::min(std::max(h->prm.score_threshold, 0), 255), 0,
+                       h->d_mask.p, A, g, h->d_tiles.p,
+                       std::min(std::max(h->distribute_mode ? h->distribute_low : h->prm.score_threshold, 0), 255), 0,
                        h->d_chunk_counts_p, h->emit_per);
     T.end(ST_FAST, s);
     // forked here, not right after the pyramid: FAST fills the chip by itself, emission and selection do not
@@ -705,6 +712,7 @@ void orbx_extractor_destroy(orbx_extractor* h) {
     h->d_select_ws.release();
     h->d_scols.release(); h->d_srows.release(); h->d_ssched.release();
     h->d_tcols.release(); h->d_trows.release(); h->d_tsched.release();
+    h->d_labels.release(); h->d_picked_idx.release(); h->d_picked_n.release();
     h->timer.destroy();
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
     if (h->ev_pyramid) (void)hipEventDestroy(h->ev_pyramid);
@@ -808,6 +816,20 @@ orbx_status orbx_detect(orbx_extractor* h, const uint8_t* image, int width, int 
     ORBX_TRY(check_image_args(h, image, width, height, stride, channels));
     ORBX_HIP(hipSetDevice(h->device));
     ORBX_TRY(drain_pending(h));
+    if (h->distribute_mode) {
+        // the distribution mode lives in the batch path: a batch of one, keypoints only
+        const size_t nbytes = (size_t)stride * height;
+        ORBX_TRY(h->d_in.ensure(nbytes));
+        ORBX_HIP(hipMemcpyAsync(h->d_in.p, image, nbytes, hipMemcpyHostToDevice, h->stream));
+        const int cap = std::max(capacity, h->prm.n_key_points + 4 * kMaxLevels);
+        std::vector<orbx_keypoint> tmp((size_t)cap);
+        int32_t n = 0;
+        ORBX_TRY(orbx_extract_batch(h, h->d_in.p, 1, nbytes, width, height, stride, channels, tmp.data(), cap, &n, nullptr));
+        *count = n;
+        if (n > capacity) return ORBX_CAPACITY;
+        std::copy(tmp.begin(), tmp.begin() + n, keypoints);
+        return ORBX_OK;
+    }
     ORBX_TRY(build_geometry(h, width, height, h->prm.level_pyramid));
     ORBX_TRY(ensure_buffers(h, 1));
     size_t bytes = (size_t)stride * height;
@@ -885,6 +907,42 @@ orbx_status orbx_compute(orbx_extractor* h, const uint8_t* image, int width, int
 }
 
 }  // extern "C"
+
+// The opt-in distribution mode: every (frame, level) chooses its keypoints from the candidate list (per-cell
+// adaptive threshold, quad-tree); k_select_frame then takes the chosen candidates instead of running the two culls.
+static orbx_status launch_distribute(orbx_extractor* h, int n_frames) {
+    const Geom& g = h->geom;
+    int max_quota = 0, cell_words = 1;
+    const int lo = std::max(3, g.edge);
+    for (int l = 0; l < g.nlevels; l++) {
+        max_quota = std::max(max_quota, g.L[l].quota);
+        const int aw = g.L[l].w - 2 * lo, ah = g.L[l].h - 2 * lo;
+        if (aw <= 0 || ah <= 0) continue;
+        const int csz = std::max(h->distribute_cell, 1);
+        const int ncol = std::max(aw / csz, 1), nrow = std::max(ah / csz, 1);
+        cell_words = std::max(cell_words, (ncol * nrow + 31) / 32);
+    }
+    DistributeParams dp;
+    dp.high_threshold = std::min(std::max(h->prm.score_threshold, 0), 255);
+    dp.cell_size = h->distribute_cell;
+    dp.max_nodes = std::max(max_quota + 4, 16);
+    dp.cell_words = cell_words;
+    dp.out_stride = dp.max_nodes;
+    if (dp.max_nodes > 60000) return ORBX_UNSUPPORTED;   // box labels are 16 bits
+    const size_t lds = sizeof(int) * ((size_t)13 * dp.max_nodes + dp.cell_words);
+    if (lds > 150 * 1024) return ORBX_UNSUPPORTED;
+    ORBX_HIP(hipFuncSetAttribute((const void*)k_distribute_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORBX_TRY(h->d_labels.ensure((size_t)h->cand_cap * n_frames));
+    ORBX_TRY(h->d_picked_idx.ensure((size_t)n_frames * kMaxLevels * dp.out_stride));
+    ORBX_TRY(h->d_picked_n.ensure((size_t)n_frames * kMaxLevels));
+    h->picked_stride = dp.out_stride;
+    ORBX_HIP(hipMemsetAsync(h->d_picked_n.p, 0, sizeof(int) * (size_t)n_frames * kMaxLevels, h->stream));
+    hipLaunchKernelGGL(k_distribute_level, dim3(g.nlevels, n_frames), dim3(kDistributeThreads), lds, h->stream,
+                       h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_totals.p, g, dp, h->d_labels.p,
+                       h->d_picked_idx.p, h->d_picked_n.p);
+    ORBX_HIP(hipGetLastError());
+    return ORBX_OK;
+}
 
 // Frames the device selection left at status 2 because the global form ran out of workspace slices (more frames
 // beyond the LDS form than slices) get further passes of the global form, a slice-load at a time; the describe stage is
@@ -1051,6 +1109,10 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
     // with the selection on the device the orientation is computed for the kept keypoints only, after it
     ORBX_TRY(run_detect_stage(h, d_images, n_frames, frame_stride, width, height, stride, channels, h->fork_blur,
                               device_path));
+    if (h->distribute_mode && !device_path) {
+        set_last_error_text("orbx_extract_batch: the distribution mode needs the selection on the device");
+        return ORBX_UNSUPPORTED;
+    }
     if (device_path) {
         h->kp_cap = capacity;
         ORBX_TRY(h->d_kp_src.ensure((size_t)capacity * n_frames));
@@ -1094,11 +1156,19 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         h->sel_ws_stride = ws_stride;
         h->sel_ws_slices = ws_slices;
         h->timer.begin(ST_SELECT, h->stream);
+        const int* picked_idx = nullptr;
+        const int* picked_n = nullptr;
+        if (h->distribute_mode) {
+            ORBX_TRY(launch_distribute(h, n_frames));
+            picked_idx = h->d_picked_idx.p;
+            picked_n = h->d_picked_n.p;
+        }
         auto launch_global = [&](int pass) {
             hipLaunchKernelGGL(k_select_frame<true>, dim3(n_frames), dim3(64 * h->geom.nlevels), 0, h->stream,
                                h->d_cand.p, h->cand_cap, h->d_level_counts_p, h->d_totals.p, h->geom, fm, h->d_kp.p,
                                capacity, h->d_kp_counts.p, h->d_cell_start.p, h->d_cell_items.p, h->d_status.p,
-                               h->cand_cap, pass, h->d_select_ws.p, ws_stride, ws_slices, ws_counter, h->d_kp_src.p);
+                               h->cand_cap, pass, h->d_select_ws.p, ws_stride, ws_slices, ws_counter, h->d_kp_src.p,
+                               picked_idx, picked_n, h->picked_stride);
         };
         if (lds_form) {
             const size_t shmem = select_lds(kSelectMaxCands);
@@ -1117,15 +1187,18 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
                                    select_lds(max_cands), h->stream, h->d_cand.p, h->cand_cap, h->d_level_counts_p,
                                    h->d_totals.p, h->geom, fm, h->d_kp.p, capacity, h->d_kp_counts.p,
                                    h->d_cell_start.p, h->d_cell_items.p, h->d_status.p, max_cands, pass, nullptr, 0, 0,
-                                   nullptr, h->d_kp_src.p);
+                                   nullptr, h->d_kp_src.p, picked_idx, picked_n, h->picked_stride);
             };
-            if (two_tier) {
+            if (picked_idx) {
+                // the chosen keypoints of a frame are few: one launch of the small form takes every frame
+                launch_select(two_tier && small_cands >= capacity + 4 * h->geom.nlevels ? small_cands : kSelectMaxCands, -1);
+            } else if (two_tier) {
                 launch_select(small_cands, 0);
                 launch_select(kSelectMaxCands, 1);
             } else {
                 launch_select(kSelectMaxCands, -1);
             }
-            launch_global(2);  // frames the LDS form could not hold
+            if (!picked_idx) launch_global(2);  // frames the LDS form could not hold
         } else {
             launch_global(-1);
         }
@@ -1165,6 +1238,11 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         for (int f = 0; f < n_frames; f++) {
             if (h_status[f] == 1) return ORBX_CAPACITY;
             if (h_status[f] == 2) redo = true;
+        }
+        if (redo && h->distribute_mode) {
+            set_last_error_text("orbx_extract_batch: a frame has more corners at the low threshold than the candidate "
+                                "list holds; the distribution mode has no host path to enlarge it");
+            return ORBX_UNSUPPORTED;
         }
         if (redo) {
             int left = 0;
@@ -1220,6 +1298,11 @@ orbx_status orbx_extractor_finish(orbx_extractor* h, int32_t* counts, int* redon
         if (counts) std::memcpy(counts, h_cnt, sizeof(int) * a.n_frames);
         return ORBX_OK;
     }
+    if (h->distribute_mode) {
+        set_last_error_text("orbx_extractor_finish: a frame has more corners at the low threshold than the candidate "
+                            "list holds; the distribution mode has no host path to enlarge it");
+        return ORBX_UNSUPPORTED;
+    }
     // frames were left over (more of them beyond the LDS form than workspace slices, or a candidate list that
     // overflowed): the batch is finished by further device passes or, for an overflowed list, by the host path, and
     // whatever consumed the device results in the meantime has to run again
@@ -1255,6 +1338,24 @@ orbx_status orbx_extractor_set_frame_model(orbx_extractor* h, const orbx_camera*
     h->has_grid = grid != nullptr;
     if (camera) h->camera = *camera;
     if (grid) h->grid = *grid;
+    return ORBX_OK;
+}
+
+orbx_status orbx_extractor_set_distribution(orbx_extractor* h, int mode, int low_threshold, int cell_size) {
+    ORBX_ENTER(h);
+    if (mode != 0 && mode != 1) return ORBX_BAD_ARG;
+    if (mode == 1 && (low_threshold < 1 || low_threshold > 255 || low_threshold > std::max(h->prm.score_threshold, 1) ||
+                      cell_size < 8 || cell_size > 4096))
+        return ORBX_BAD_ARG;
+    ORBX_HIP(hipSetDevice(h->device));
+    ORBX_TRY(drain_pending(h));
+    h->distribute_mode = mode;
+    if (mode == 1) {
+        h->distribute_low = low_threshold;
+        h->distribute_cell = cell_size;
+    }
+    h->pyramid_valid = false;
+    h->cached_image.valid = false;
     return ORBX_OK;
 }
 

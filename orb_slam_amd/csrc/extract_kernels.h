@@ -1560,7 +1560,10 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
                                                         int* __restrict__ cell_items, int* __restrict__ status,
                                                         int max_cands, int pass, unsigned char* __restrict__ ws,
                                                         size_t ws_stride, int ws_slices,
-                                                        int* __restrict__ ws_counter, int* __restrict__ kp_src) {
+                                                        int* __restrict__ ws_counter, int* __restrict__ kp_src,
+                                                        const int* __restrict__ picked_idx = nullptr,
+                                                        const int* __restrict__ picked_n = nullptr,
+                                                        int picked_stride = 0) {
     extern __shared__ __align__(16) unsigned char s_lds[];
     __shared__ int s_n[kMaxLevels], s_off[kMaxLevels], s_cnt, s_slice;
     typedef typename std::conditional<GLOBAL, uint32_t, uint16_t>::type St;
@@ -1586,7 +1589,15 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
     St* s_rp = s_lp + max_cands;                                                 // [max_cands]
     const int tid = threadIdx.x, lane = tid & 63, lvl = tid >> 6;
     const Cand* cd = cand + (size_t)b * cand_cap;
-    const int total = totals[b];
+    // picked_idx: the opt-in distribution mode (k_distribute_level) has already chosen every level's keypoints; both
+    // culls are skipped and only the chosen candidates enter the working arrays
+    const bool picked = picked_idx != nullptr;
+    int total = totals[b];
+    const bool overflowed = picked && total > cand_cap;   // the candidate list itself: k_distribute_level chose nothing
+    if (picked) {
+        total = 0;
+        for (int j = 0; j < g.nlevels; j++) total += picked_n[b * kMaxLevels + j];
+    }
     // pass 0: the launch with the small LDS leaves frames that do not fit it to pass 1 (status 3); pass 1 takes only
     // those; pass -1 is a single launch for every frame; pass 2 (global form) takes the frames an LDS launch left
     // A frame this launch cannot finish leaves no keypoints and an EMPTY grid: whatever is queued behind the batch
@@ -1599,17 +1610,26 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
         }
         if (tid == 0) { status[b] = st; kp_counts[b] = 0; }
     };
+    if (overflowed) {
+        leave_empty(2);
+        return;
+    }
     if (total > max_cands || total > cand_cap) {
         leave_empty((pass == 0 && total <= cand_cap) ? 3 : 2);
         return;
     }
     int n = 0, off = 0;
+    const int* per_level = picked ? picked_n : level_counts;
     if (lvl < g.nlevels) {
-        n = level_counts[b * kMaxLevels + lvl];
-        for (int j = 0; j < lvl; j++) off += level_counts[b * kMaxLevels + j];
+        n = per_level[b * kMaxLevels + lvl];
+        for (int j = 0; j < lvl; j++) off += per_level[b * kMaxLevels + j];
+    }
+    if (picked && lvl < g.nlevels) {
+        const int* mine = picked_idx + ((size_t)b * kMaxLevels + lvl) * picked_stride;
+        for (int i = lane; i < n; i += 64) s_el[off + i] = stdsel::Elem{0.f, min(max(mine[i], 0), cand_cap - 1)};
     }
     // the levels' candidates are one contiguous list: all wavefronts load it together, four loads in flight per lane
-    for (int base = 0; base < total; base += 4 * (int)blockDim.x) {
+    for (int base = 0; !picked && base < total; base += 4 * (int)blockDim.x) {
         int sc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1623,9 +1643,10 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
         }
     }
     __syncthreads();
-    if (lvl < g.nlevels) n = stdsel::wave_retain_best(s_el + off, n, 2 * g.L[lvl].quota, s_lp + off, s_rp + off, lane);
+    if (!picked && lvl < g.nlevels)
+        n = stdsel::wave_retain_best(s_el + off, n, 2 * g.L[lvl].quota, s_lp + off, s_rp + off, lane);
     __syncthreads();
-    if (lvl < g.nlevels)
+    if (!picked && lvl < g.nlevels)
         for (int base = 0; base < n; base += 256) {   // four gathers in flight per lane
             int ix[4];
             float hv[4];
@@ -1642,7 +1663,7 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
         }
     __syncthreads();
     if (lvl < g.nlevels) {
-        n = stdsel::wave_retain_best(s_el + off, n, g.L[lvl].quota, s_lp + off, s_rp + off, lane);
+        if (!picked) n = stdsel::wave_retain_best(s_el + off, n, g.L[lvl].quota, s_lp + off, s_rp + off, lane);
         if (lane == 0) s_n[lvl] = n;
     }
     __syncthreads();
@@ -1667,7 +1688,7 @@ __global__ __launch_bounds__(1024) void k_select_frame(const Cand* __restrict__ 
             k.y = (float)c.y * sf;
             k.size = fm.patch_size * sf;
             k.angle = c.angle;
-            k.response = c.harris;
+            k.response = picked ? (float)c.score : c.harris;   // the distribution mode ranks by corner score
             k.octave = lvl;
             // with kp_src the orientation is computed after this kernel, for the kept keypoints only: where the
             // keypoint was detected travels in class_id until the final store

@@ -34,7 +34,7 @@ SYMBOLS = [
     "orbx_probe_issue_rate", "orbx_match_projection_points_batch", "orbx_extractor_finish", "orbx_extractor_set_image_cache",
     "orbx_extractor_set_device_select", "orbx_extractor_set_blur_fork", "orbx_extractor_set_stream", "orbx_matcher_set_stream", "orbx_ransac_set_stream", "orbx_matcher_set_hamming_kernel",
     "orbx_normalize_points", "orbx_fundamental_npt", "orbx_homography_dlt", "orbx_ransac_set_fork",
-    "orbx_selftest_stream_pyramid", "orbx_extractor_set_pyramid_kernel", "orbx_extractor_set_pyramid_tail",
+    "orbx_selftest_stream_pyramid", "orbx_extractor_set_pyramid_kernel", "orbx_extractor_set_pyramid_tail", "orbx_extractor_set_distribution",
 ]
 
 
@@ -232,6 +232,11 @@ class Extractor:
     def set_blur_fork(self, enabled):
         """Blur of a batch on the handle's side stream (default) or in line (several batches in flight)."""
         _check(lib().orbx_extractor_set_blur_fork(self._h, int(bool(enabled))), "orbx_extractor_set_blur_fork")
+
+    def set_distribution(self, mode, low_threshold=7, cell_size=30):
+        """mode 1: per-cell adaptive FAST threshold + quad-tree distribution (opt-in; 0 = cv::ORB's selection)."""
+        _check(lib().orbx_extractor_set_distribution(self._h, mode, low_threshold, cell_size),
+               "orbx_extractor_set_distribution")
 
     def set_pyramid_tail(self, base_level, rows_per_step=0):
         """Levels above base_level in one launch (0 = off): see orbx_extractor_set_pyramid_tail."""

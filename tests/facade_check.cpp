@@ -7,6 +7,7 @@
 #include <orb_slam/initializer.h>
 
 #include <map>
+#include <set>
 #include <memory>
 #include <thread>
 
@@ -222,6 +223,25 @@ int main(int argc, char** argv) {
     std::vector<cv::DMatch> m;
     mt.match(d1, d2, m, true);
     std::printf("kp=%zu desc=%d matches=%zu levels=%d sf1=%.9g\n", k1.size(), d1.rows, m.size(), ex.levels(), ex.scaleFactors()[1]);
+    {
+        // the three additive keys: the same class with per-cell adaptive thresholds and the quad-tree distribution
+        ros::NodeHandle nh_q = nh;
+        nh_q.set("orb_slam/orb_extractor/distribution", "1");
+        nh_q.set("orb_slam/orb_extractor/low_score_threshold", "7");
+        nh_q.set("orb_slam/orb_extractor/distribution_cell_size", "30");
+        ORBExtractor exq(nh_q, 640, 480);
+        std::vector<cv::KeyPoint> kq;
+        cv::Mat dq;
+        exq.detect(img, kq);
+        exq.compute(img, kq, dq);
+        std::set<int> cells_q, cells_o;
+        for (auto& k : kq) cells_q.insert((int)k.pt.x / 40 + 100 * ((int)k.pt.y / 40));
+        for (auto& k : k1) cells_o.insert((int)k.pt.x / 40 + 100 * ((int)k.pt.y / 40));
+        float max_resp = 0;
+        for (auto& k : kq) max_resp = std::max(max_resp, k.response);
+        std::printf("dist_kp=%zu dist_desc=%d dist_cells=%zu orb_cells=%zu dist_max_response=%.0f\n", kq.size(), dq.rows,
+                    cells_q.size(), cells_o.size(), max_resp);
+    }
     {
         auto fa = std::make_shared<MockFrame>(), fb = std::make_shared<MockFrame>();
         fa->kps = k1; fa->desc = d1; fb->kps = k2; fb->desc = d2;

@@ -54,6 +54,7 @@ orbx_status orbx_extractor_create(const orbx_extractor_params*, int, int, int, i
     return ORBX_OK;
 }
 void orbx_extractor_destroy(orbx_extractor* h) { delete h; }
+orbx_status orbx_extractor_set_distribution(orbx_extractor*, int, int, int) { return ORBX_OK; }
 orbx_status orbx_extractor_scale_tables(const orbx_extractor*, float* a, float* b, float* c, float* d, float* e) {
     a[0] = b[0] = c[0] = d[0] = 1.f;
     *e = 0.f;

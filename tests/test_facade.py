@@ -116,5 +116,12 @@ def test_facade_runs_on_gpu(tmp_path):
     assert abs(float(pose.split("r00=")[1].split()[0]) - 0.9988) < 2e-3   # cos(0.05)
     assert float(pose.split("tx=")[1].split()[0]) > 0.9                   # t = (0.3, 0.02, 0.05) normalised
     assert "two_threads_same=1" in out and "seam_same_F=1" in out
+    # the additive distribution keys: about as many keypoints, responses are corner scores (<= 255), wider coverage
+    dist = out.split("dist_kp=")[1]
+    n_dist = int(dist.split()[0])
+    # (the check image gives cv::ORB fewer corners than its quota on the coarse levels; the low threshold fills them)
+    assert kp - 50 <= n_dist <= 1000 + 3 * 8 and int(dist.split("dist_desc=")[1].split()[0]) == n_dist
+    assert int(dist.split("dist_cells=")[1].split()[0]) >= int(dist.split("orb_cells=")[1].split()[0])
+    assert 0 < float(dist.split("dist_max_response=")[1].split()[0]) <= 255
     # the homography branch fails as the reference's does until the additive switch is set
     assert "h_default=0 untouched=1 h_switch=1 h_shape_ok=1 h_det_ok=1" in out

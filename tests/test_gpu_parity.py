@@ -351,6 +351,76 @@ def test_extract_batch_equals_per_frame(oracle, test_images):
     ex.close()
 
 
+def test_distribution_mode_bit_exact(oracle, test_images):
+    """orbx_extractor_set_distribution (opt-in, no counterpart in the reference): per-cell adaptive FAST threshold +
+    quad-tree distribution.  The rule is stated sequentially in oracle/distribute_oracle.cpp (a self-oracle); the
+    device path must give the same keypoints in the same order, and the same descriptors, for colour and gray frames,
+    odd sizes, several quotas (far below and far above the number of corners), cell sizes and low thresholds, a
+    frame without a corner, a frame model, and must return to cv::ORB's selection when switched off."""
+    import torch
+    blank = np.full((480, 640, 3), 90, np.uint8)
+    cases = [("vga", [test_images[0], test_images[1], synth_image(61, 640, 480, 3), blank], 1000, 8, 7, 30),
+             ("few", [test_images[1], synth_image(62, 640, 480, 3)], 120, 4, 12, 20),
+             ("many", [test_images[0], synth_image(63, 640, 480, 3)], 8000, 8, 5, 45),
+             ("odd_gray", [synth_image(64, 401, 299), synth_image(65, 401, 299)], 300, 5, 7, 30),
+             ("wide", [synth_image(66, 1100, 260, 3)], 600, 3, 9, 25)]
+    for name, frames, nkp, nlevels, low, cell in cases:
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else 3
+        p = oracle.orb_params(nfeatures=nkp, nlevels=nlevels)
+        ex = orbx.Extractor(n_key_points=nkp, level_pyramid=nlevels, max_width=w, max_height=h, max_batch=len(frames))
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        torch.cuda.synchronize()
+        cap = nkp + 4 * nlevels + 64
+        ex.set_distribution(1, low, cell)
+        kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), w * h * ch, w, h, w * ch, ch, cap)
+        spread, first = [], None
+        for f, img in enumerate(frames):
+            ok_ = oracle.detect_distributed(p, img, low, cell)
+            ok2, od = oracle.compute(p, img, ok_)
+            first = ok2 if f == 0 else first
+            assert counts[f] == len(ok2), (name, f, counts[f], len(ok2))
+            assert np.array_equal(kps[f, :counts[f]], ok2.astype(orbx.KP_DTYPE)), (name, f)
+            assert np.array_equal(desc[f, :counts[f]], od), (name, f)
+            spread.append(len({(int(x) // 40, int(y) // 40) for x, y in zip(ok2["x"], ok2["y"])}))
+        # one host frame through orbx_detect: a batch of one (so the border filter of the describe stage has run)
+        k1 = ex.detect(frames[0])
+        assert np.array_equal(k1, first.astype(orbx.KP_DTYPE)), name
+        # switched off again: cv::ORB's selection
+        ex.set_distribution(0)
+        kps0, counts0, desc0 = ex.extract_batch(dev.data_ptr(), len(frames), w * h * ch, w, h, w * ch, ch, cap)
+        for f, img in enumerate(frames):
+            ok2, od = oracle.compute(p, img, oracle.detect(p, img))
+            assert counts0[f] == len(ok2) and np.array_equal(kps0[f, :counts0[f]], ok2.astype(orbx.KP_DTYPE)), (name, f)
+            assert np.array_equal(desc0[f, :counts0[f]], od), (name, f)
+            if name == "vga" and counts0[f] > 500:
+                # the point of the mode: the keypoints cover more of the image
+                assert spread[f] > len({(int(x) // 40, int(y) // 40) for x, y in zip(ok2["x"], ok2["y"])}), (name, f)
+        ex.close()
+    # with the frame model of MonoFrame::extractFeatures (undistortion + bucket grid) on a larger batch
+    frames = [test_images[i % 2] if i % 3 == 0 else synth_image(700 + i, 640, 480, 3) for i in range(40)]
+    cam = orbx.make_camera(517.3, 516.5, 318.6, 255.3, [0.2624, -0.9531, -0.0054, 0.0026, 1.1633])
+    grid = orbx.make_grid((10.8, 626.0, 14.7, 473.3))
+    ex = orbx.Extractor(n_key_points=1000, level_pyramid=8, max_width=640, max_height=480, max_batch=len(frames))
+    ex.set_frame_model(cam, grid)
+    ex.set_distribution(1, 7, 30)
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    torch.cuda.synchronize()
+    kps, counts, desc = ex.extract_batch(dev.data_ptr(), len(frames), 640 * 480 * 3, 640, 480, 640 * 3, 3, 1280)
+    p = oracle.orb_params(nfeatures=1000, nlevels=8)
+    ocam = oracle.camera(517.3, 516.5, 318.6, 255.3, [0.2624, -0.9531, -0.0054, 0.0026, 1.1633], 640, 480)
+    og = oracle.grid_params((10.8, 626.0, 14.7, 473.3))
+    for f in (0, 1, 7, 39):
+        k = oracle.detect_distributed(p, frames[f], 7, 30)
+        xy = oracle.undistort_points(ocam, np.stack([k["x"], k["y"]], 1))
+        k["x"], k["y"] = xy[:, 0], xy[:, 1]
+        k, start, items = oracle.assign_grid(og, k)
+        k, d = oracle.compute(p, frames[f], k)
+        assert counts[f] == len(k) and np.array_equal(kps[f, :counts[f]], k.astype(orbx.KP_DTYPE)), f
+        assert np.array_equal(desc[f, :counts[f]], d), f
+    ex.close()
+
+
 def test_pyramid_tail_kernel_bit_exact(oracle, test_images):
     """orbx_extractor_set_pyramid_tail: the levels above a base level in one launch (a workgroup per frame reads the
     base level from the atlas and walks the rest through LDS rings).  The atlas must equal the oracle's pyramid,

@@ -283,3 +283,46 @@ def test_pose_oracle_recovers_planted_motions(oracle):
     R, t, nrm = oracle.decompose_homography(np.eye(3, dtype=np.float32) * 2.5, K)
     assert len(R) == 1 and np.allclose(R[0], np.eye(3), atol=1e-12) and not t.any() and not nrm.any()
 
+
+def test_distribution_rule_properties(oracle):
+    """oracle/distribute_oracle.cpp defines the opt-in distribution mode (no counterpart in the reference).  What the
+    rule promises, on random corner sets: kept corners are distinct and active (strong, or in a cell without a strong
+    corner); with a quota at or above the number of active corners every one of them is kept; below it the level
+    keeps quota .. quota + 2; and where the strong corners crowd one part of the image the kept set covers more
+    coarse cells than the same number of strongest corners would."""
+    rng = np.random.default_rng(17)
+    w, h, lo, cell, high = 640, 480, 31, 30, 20
+    for trial in range(30):
+        n = int(rng.integers(1, 3000))
+        pos = rng.choice((w - 2 * lo) * (h - 2 * lo), n, replace=False)
+        pos.sort()   # raster order
+        ys, xs = pos // (w - 2 * lo) + lo, pos % (w - 2 * lo) + lo
+        if trial % 3 == 0:    # clustered: most corners in one corner of the image
+            xs = (lo + (xs - lo) // 4).astype(np.int64)
+            key = ys * w + xs
+            _, first = np.unique(key, return_index=True)
+            xs, ys = xs[np.sort(first)], ys[np.sort(first)]
+            n = len(xs)
+        scores = rng.integers(7, 90, n)
+        if trial % 3 == 1:    # the strong corners sit in the left third of the image
+            scores = np.where(xs < w // 3, rng.integers(100, 200, n), rng.integers(7, 60, n))
+        aw, ah = w - 2 * lo, h - 2 * lo
+        ncol, nrow = max(aw // cell, 1), max(ah // cell, 1)
+        wc, hc = -(-aw // ncol), -(-ah // nrow)
+        cid = np.minimum((ys - lo) // hc, nrow - 1) * ncol + np.minimum((xs - lo) // wc, ncol - 1)
+        strong_cells = set(cid[scores >= high].tolist())
+        active = np.array([s >= high or c not in strong_cells for s, c in zip(scores, cid)])
+        for quota in (1, 7, 50, 217, n + 5):
+            kept = oracle.quadtree_select(xs, ys, scores, w, h, lo, quota, high, cell)
+            assert len(set(kept.tolist())) == len(kept) and active[kept].all(), (trial, quota)
+            n_act = int(active.sum())
+            if quota >= n_act:
+                assert sorted(kept.tolist()) == np.flatnonzero(active).tolist(), (trial, quota)
+            else:
+                assert quota <= len(kept) <= quota + 2 or len(kept) == 1, (trial, quota, len(kept))
+            if 7 < quota < n_act // 4 and trial % 3 == 1:
+                # where a cull by strength would stay in the strong third, the quad-tree covers the image
+                top = np.argsort(-scores[active], kind="stable")[:len(kept)]
+                cover = lambda ix, iy: len(set(zip((ix // 60).tolist(), (iy // 60).tolist())))
+                assert cover(xs[kept], ys[kept]) > cover(xs[active][top], ys[active][top]), (trial, quota)
+
