@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--pyramid-kernel", type=int, default=0,
                     help="0 / 1: level by level (the default), 2: the one-pass kernel")
     ap.add_argument("--pyramid-rows", type=int, default=0, help="image rows per step of the one-pass pyramid kernel")
+    ap.add_argument("--distribution", type=int, default=0,
+                    help="1: the opt-in per-cell adaptive threshold + quad-tree distribution (low threshold 7, cells of "
+                         "30 px) instead of cv::ORB's selection; not the headline configuration")
     ap.add_argument("--pyramid-tail", type=int, default=0,
                     help="levels above this one in one launch (orbx_extractor_set_pyramid_tail; 0 = level by level)")
     ap.add_argument("--pyramid-tail-rows", type=int, default=0)
@@ -230,6 +233,8 @@ def main():
                 self.ex.set_pyramid_kernel(args.pyramid_kernel, args.pyramid_rows)
             if args.pyramid_tail:
                 self.ex.set_pyramid_tail(args.pyramid_tail, args.pyramid_tail_rows)
+            if args.distribution:
+                self.ex.set_distribution(args.distribution, 7, 30)
             self.mt = orbx.Matcher(device=local_rank)
             self.mt.set_stream(self.tstream.cuda_stream)
             self.sf = self.ex.scale_tables()[1]
@@ -634,6 +639,7 @@ def main():
                                    "test image + noise), 1000 kp, 8 levels x1.2: per-frame extract (detect, "
                                    "undistort, 64x64 grid, compute) + windowed match (radius 15) to the previous frame",
                        "frames_per_gpu_per_step": B, "batches_in_flight": len(pipes), "mean_keypoints": mean_kp,
+                       "keypoint_selection": "adaptive threshold + quad-tree (opt-in)" if args.distribution else "cv::ORB",
                        "mean_window_matches": mean_matches,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": roofline, "roofline_ransac": roofline_ransac, "roofline_match": roofline_match,

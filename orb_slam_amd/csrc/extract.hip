@@ -404,7 +404,10 @@ void run_emit_and_harris(orbx_extractor* h, int frames, bool split = false) {
     }
     T.end(ST_EMIT, s);
     T.begin(ST_HARRIS, s);
-    if (split) {
+    if (split && h->distribute_mode) {
+        // the distribution mode ranks by corner score: no Harris response is needed
+        h->harris_split = true;
+    } else if (split) {
         const int chunks = frames >= 64 ? 16 : 128;
         hipLaunchKernelGGL(k_harris, dim3(8 * chunks * div_up(frames, 8)), dim3(256), 0, s, h->d_atlas.p, A, g,
                            h->d_cand.p, h->cand_cap, h->d_totals.p, h->d_thresholds.p, h->harris_scale_sq_sq, chunks,
