@@ -356,6 +356,24 @@ def main():
     if alone_avg:
         roofline["stage_ms_per_batch_alone"] = alone_avg
         roofline["frac_alone"] = per_kernel[dom] * B / (alone_avg[dom] * 1e-3) / 1e9 / 8000.0
+    # what the dominant kernel's instruction pipes do while it runs alone: the counters of the PMC passes kept under
+    # profiles/ (per launch of the same batch size) against this run's duration of the kernel alone.  Nominal
+    # capacities: 1024 SIMDs issuing one vector instruction per 2.5 cycles (the probed full rate), one scalar unit and
+    # one LDS per CU (256), 2.4 GHz.
+    try:
+        rd = lambda name: json.load(open(os.path.join(ROOT, "profiles", args.profile_round + name))).get(kernel_of[dom], {})
+        sq_i, sq_m = rd("_pmc_sq.json"), rd("_pmc_sq_mem.json")
+        ms_alone = (alone_avg or stage_avg)[dom] / launches[dom]
+        cyc = ms_alone * 1e-3 * 2.4e9
+        roofline["pipes_alone"] = {
+            "vector_issue": sq_i["SQ_INSTS_VALU_per_launch"] * 2.5 / (cyc * 1024),
+            "scalar_issue": sq_i["SQ_INSTS_SALU_per_launch"] / (cyc * 256),
+            "lds_active": sq_m["SQ_LDS_IDX_ACTIVE_per_launch"] / (cyc * 256),
+            "lds_bank_conflict_share": sq_m["SQ_LDS_BANK_CONFLICT_per_launch"] / max(sq_m["SQ_LDS_IDX_ACTIVE_per_launch"], 1.0),
+            "note": "fractions of each pipe's cycles while the kernel runs alone; no pipe saturated means the kernel "
+                    "waits on the dependencies between its phases"}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        pass
 
     # RANSAC hypotheses/s (second half of the headline metric): 200 iterations x 2000 correspondences per pair
     ransac = None
