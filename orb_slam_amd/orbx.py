@@ -73,7 +73,7 @@ class OrbxError(RuntimeError):
         self.status = status
         msg = lib().orbx_status_string(status).decode()
         detail = lib().orbx_last_error().decode()
-        super().__init__(f"{where}: {msg}" + (f" ({detail})" if detail and status in (DEVICE, CAPACITY, BUSY) else ""))
+        super().__init__(f"{where}: {msg}" + (f" ({detail})" if detail and status in (DEVICE, CAPACITY, BUSY, UNSUPPORTED) else ""))
 
 
 _lib = None

@@ -397,6 +397,20 @@ def test_distribution_mode_bit_exact(oracle, test_images):
                 # the point of the mode: the keypoints cover more of the image
                 assert spread[f] > len({(int(x) // 40, int(y) // 40) for x, y in zip(ok2["x"], ok2["y"])}), (name, f)
         ex.close()
+    # more corners than the candidate list holds (the dot lattice of test_more_corners_than_the_candidate_list_holds:
+    # one corner per 12 pixels).  cv::ORB's selection enlarges the list on the host path; the distribution mode has no
+    # host path and must refuse the batch, not truncate it
+    dots = np.zeros((480, 640), np.uint8)
+    for b in range(480 // 3):
+        dots[3 * b, (2 * b) % 4::4] = 255
+    ex = orbx.Extractor(n_key_points=500, level_pyramid=1, max_width=640, max_height=480, max_batch=2)
+    dev = torch.from_numpy(np.stack([synth_image(67, 640, 480), dots])).cuda()
+    torch.cuda.synchronize()
+    ex.set_distribution(1, 7, 30)
+    with pytest.raises(orbx.OrbxError) as e:
+        ex.extract_batch(dev.data_ptr(), 2, 640 * 480, 640, 480, 640, 1, 800)
+    assert e.value.status == orbx.UNSUPPORTED
+    ex.close()
     # with the frame model of MonoFrame::extractFeatures (undistortion + bucket grid) on a larger batch
     frames = [test_images[i % 2] if i % 3 == 0 else synth_image(700 + i, 640, 480, 3) for i in range(40)]
     cam = orbx.make_camera(517.3, 516.5, 318.6, 255.3, [0.2624, -0.9531, -0.0054, 0.0026, 1.1633])
