@@ -151,7 +151,9 @@ def main():
                     help="frames per GPU per step (792 = one TUM fr1/xyz-length sequence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ransac-pairs", type=int, default=1024)
-    ap.add_argument("--streams", type=int, default=2, help="independent batches in flight per GPU")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent batches in flight per GPU, each on a HIP stream of its own (high priority unless "
+                         "ORBX_BENCH_PRIORITIES says otherwise)")
     ap.add_argument("--kfdb-frames", type=int, default=1250,
                     help="frames per GPU of the key-frame database leg (0 = skip): every 10th is a key frame, the "
                          "ranks all-gather their key frames' descriptors and match every frame against all of them")
@@ -220,8 +222,8 @@ def main():
         Batches are independent, so several pipelines keep the GPU busy while one of them sits in a
         latency-bound kernel (ordered emission, selection, the greedy resolve) or in its end-of-batch hand-off."""
 
-        def __init__(self):
-            self.tstream = torch.cuda.Stream(device=device)
+        def __init__(self, priority=0):
+            self.tstream = torch.cuda.Stream(device=device, priority=priority)
             self.ex = orbx.Extractor(n_key_points=NKP, level_pyramid=NLEVELS, max_width=W, max_height=H, max_batch=B,
                                      device=local_rank)
             self.ex.set_frame_model(cam, grid)
@@ -270,7 +272,15 @@ def main():
                         stage_ms.setdefault(k, []).append(v)
                     match_ms.append((e0, e1))
 
-    pipes = [Pipeline() for _ in range(max(1, args.streams))]
+    # Three batches on high-priority streams.  Measured on 792-frame VGA batches (ms per step, several runs each; the HIP
+    # runtime spreads its streams over GPU_MAX_HW_QUEUES = 4 hardware queues by default): two default-priority streams
+    # 3.42-3.60 depending on which queues they land on, three 3.56, three high-priority ones 3.34-3.44; with 3 hardware
+    # queues two or three default streams give 3.38-3.48, with 1 or 2 queues every kernel runs alone (3.85), with 8 or 16
+    # every stream has a queue of its own and the step takes 3.7-4.05: two kernels sharing the chip with a third
+    # queued behind them without a gap is the arrangement that pays, free concurrency of everything is not.
+    # (ORBX_BENCH_PRIORITIES="0,0,0": stream priority per pipeline, for that experiment.)
+    prios = [int(v) for v in os.environ.get("ORBX_BENCH_PRIORITIES", "").split(",") if v.strip()]
+    pipes = [Pipeline(prios[i] if i < len(prios) else -1) for i in range(max(1, args.streams))]
 
     def run_steps(n, record):
         """n steps in all, dealt round-robin to the pipelines; each pipeline is driven by its own host thread
@@ -656,7 +666,9 @@ def main():
             "config": {"workload": "TUM-fr1-like monocular 640x480 BGR sequence, one sequence per step (homography walk of the reference "
                                    "test image + noise), 1000 kp, 8 levels x1.2: per-frame extract (detect, "
                                    "undistort, 64x64 grid, compute) + windowed match (radius 15) to the previous frame",
-                       "frames_per_gpu_per_step": B, "batches_in_flight": len(pipes), "mean_keypoints": mean_kp,
+                       "frames_per_gpu_per_step": B, "batches_in_flight": len(pipes),
+                       "stream_priorities": [(prios[i] if i < len(prios) else -1) for i in range(len(pipes))],
+                       "mean_keypoints": mean_kp,
                        "keypoint_selection": "adaptive threshold + quad-tree (opt-in)" if args.distribution else "cv::ORB",
                        "mean_window_matches": mean_matches,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
