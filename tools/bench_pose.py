@@ -48,3 +48,33 @@ for _ in range(3):
 dt = (time.perf_counter() - t0) / 3
 print('CPU oracle, one pair: %.2f ms -> %.0f pairs/s; equal to device: %s' %
       (dt * 1e3, 1 / dt, np.array_equal(oR, Rr[0]) and np.array_equal(o3, xyz[:n])))
+
+# the homography branch (opt-in in the facade): decomposition + visibility filter for the same point sets
+Hm = np.array([[1.01, 0.01, 3.0], [-0.01, 0.99, -2.0], [1e-5, -1e-5, 1.0]], np.float32)
+Hs = np.stack([Hm] * P)
+for _ in range(2):
+    hR, ht, hidx, hall, hn = rs.recover_pose_homography_batch(Hs, K, pts_all, ref_all, start)
+t0 = time.perf_counter()
+for _ in range(N):
+    hR, ht, hidx, hall, hn = rs.recover_pose_homography_batch(Hs, K, pts_all, ref_all, start)
+dt = (time.perf_counter() - t0) / N
+oR4, ot4, on4 = O.decompose_homography(Hm, K)
+print('homography pose: %.2f ms per %d pairs (%.0f pairs/s); motions equal to the oracle: %s' %
+      (dt * 1e3, P, P / dt, np.array_equal(hall[0, :, :9].reshape(4, 3, 3), oR4)))
+
+# the public n-point solvers: 1024 systems of 79 correspondences (the size of the reference's own test)
+m = 79
+sp = rng.uniform(0, 640, (P, m, 2)).astype(np.float32)
+sr = (sp + rng.normal(0, 2, (P, m, 2))).astype(np.float32)
+for _ in range(2):
+    Fn = rs.fundamental_npt(sp, sr)
+    Hn = rs.homography_dlt(sp, sr)
+t0 = time.perf_counter()
+for _ in range(N):
+    Fn = rs.fundamental_npt(sp, sr)
+t1 = time.perf_counter()
+for _ in range(N):
+    Hn = rs.homography_dlt(sp, sr)
+t2 = time.perf_counter()
+print('n-point solvers, %d systems x %d points: F %.2f ms, H %.2f ms per call (host pointers in and out)' %
+      (P, m, (t1 - t0) / N * 1e3, (t2 - t1) / N * 1e3))
