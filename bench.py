@@ -364,8 +364,19 @@ def main():
                 "stage_ms_per_batch": stage_avg, "algorithmic_bytes_per_frame": frame_bytes,
                 "device_ms_per_batch": float(sum(stage_avg.values()))}
     if alone_avg:
+        # With several batches in flight a HIP-event bracket around a launch also holds the time the launch waits behind
+        # the other batches' kernels on the hardware queues, and the kernel itself is stretched by whatever shares the
+        # chip with it: that figure says how the schedule treats the kernel, not how close the kernel is to its
+        # roofline.  `achieved` / `frac` are therefore taken from the same batch run alone right after the timed region
+        # (HIP events on the library's stream; `profiles/*_kernel_stats_streams1.csv` is the rocprofv3 view of the same
+        # thing); the bracket inside the timed region is kept beside it.
         roofline["stage_ms_per_batch_alone"] = alone_avg
-        roofline["frac_alone"] = per_kernel[dom] * B / (alone_avg[dom] * 1e-3) / 1e9 / 8000.0
+        alone = per_kernel[dom] * B / (alone_avg[dom] * 1e-3) / 1e9
+        roofline["timed_region"] = {"achieved": achieved, "frac": achieved / 8000.0,
+                                    "note": "HIP-event bracket of the launch with the other batches in flight"}
+        roofline["achieved"] = alone
+        roofline["frac"] = alone / 8000.0
+        roofline["frac_alone"] = alone / 8000.0
     # what the dominant kernel's instruction pipes do while it runs alone: the counters of the PMC passes kept under
     # profiles/ (per launch of the same batch size) against this run's duration of the kernel alone.  Nominal
     # capacities: 1024 SIMDs issuing one vector instruction per 2.5 cycles (the probed full rate), one scalar unit and
