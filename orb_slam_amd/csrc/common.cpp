@@ -1,6 +1,10 @@
 // Error reporting shared by the orbx translation units.
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace orbx {
 static thread_local std::string g_last_error;
 
@@ -11,6 +15,19 @@ void set_last_error(const char* what, hipError_t e, const char* file, int line) 
 }
 void set_last_error_text(const char* text) { g_last_error = text; }
 const std::string& last_error() { return g_last_error; }
+
+orbx_status ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex m;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int device = 0;
+    ORBX_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(m);
+    size_t& have = granted[std::make_pair(device, kernel)];
+    if (bytes <= have) return ORBX_OK;
+    ORBX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+    return ORBX_OK;
+}
 }  // namespace orbx
 
 extern "C" {

@@ -66,6 +66,11 @@ private:
         return ORBX_BUSY;                                                                                      \
     }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel on a device, shared by every handle of the
+// process: it must only ever be RAISED (a handle with a small request must not lower what another handle's launches
+// rely on).  Remembers the largest request per (device, kernel) and sets the attribute only above it.
+orbx_status ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 // Device allocation that remembers its size; freed by the owning handle.
 template <typename T>
 struct DevBuf {

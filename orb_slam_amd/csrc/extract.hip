@@ -116,8 +116,6 @@ struct orbx_extractor {
     size_t sel_ws_stride = 0;
     int sel_ws_slices = 0;
     bool device_select = true;     // batch path: select / undistort / grid on the device (k_select_frame)
-    bool select_attr_set = false;
-    size_t select_attr_bytes = 0;
     int last_frames = 0;
     bool pyramid_valid = false;  // atlas holds the pyramid of the frames of the last detect stage
 
@@ -188,9 +186,7 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
                                 hipMemcpyHostToDevice, h->stream));
         ORBX_HIP(hipMemcpyAsync(h->d_ssched.p, h->splan.sched.data(), h->splan.sched.size() * sizeof(short),
                                 hipMemcpyHostToDevice, h->stream));
-        if (hipFuncSetAttribute((const void*)k_pyramid_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)h->splan.lds_bytes) != hipSuccess)
-            h->splan.ok = false;
+        if (ensure_dynamic_lds((const void*)k_pyramid_stream<false>, h->splan.lds_bytes) != ORBX_OK) h->splan.ok = false;
     }
     if (h->tplan.ok) {
         ORBX_TRY(h->d_tcols.ensure(std::max<size_t>(h->tplan.cols.size(), 1)));
@@ -203,9 +199,7 @@ orbx_status build_geometry(orbx_extractor* h, int w, int hgt, int nlevels) {
                                 hipMemcpyHostToDevice, h->stream));
         ORBX_HIP(hipMemcpyAsync(h->d_tsched.p, h->tplan.sched.data(), h->tplan.sched.size() * sizeof(short),
                                 hipMemcpyHostToDevice, h->stream));
-        if (hipFuncSetAttribute((const void*)k_pyramid_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)h->tplan.lds_bytes) != hipSuccess)
-            h->tplan.ok = false;
+        if (ensure_dynamic_lds((const void*)k_pyramid_stream<true>, h->tplan.lds_bytes) != ORBX_OK) h->tplan.ok = false;
     }
     ORBX_TRY(h->d_tiles.ensure(h->tiles.size()));
     ORBX_TRY(h->d_strips.ensure(h->strips.size()));
@@ -792,8 +786,7 @@ orbx_status orbx_selftest_retain_best_device(int device, const float* keys, int 
     ORBX_TRY(d_out.ensure((size_t)n + 1));
     ORBX_HIP(hipMemcpy(d_keys.p, keys, sizeof(float) * n, hipMemcpyHostToDevice));
     const size_t shmem = (size_t)std::max(n, 1) * (sizeof(stdsel::Elem) + 2 * sizeof(uint16_t)) + 16;
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_selftest_retain_best, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)shmem));
+    ORBX_TRY(ensure_dynamic_lds((const void*)k_selftest_retain_best, shmem));
     hipLaunchKernelGGL(k_selftest_retain_best, dim3(1), dim3(64), shmem, 0, d_keys.p, n, n_points, d_out.p + 1, d_out.p);
     ORBX_HIP(hipGetLastError());
     ORBX_HIP(hipDeviceSynchronize());
@@ -934,7 +927,7 @@ static orbx_status launch_distribute(orbx_extractor* h, int n_frames) {
     if (dp.max_nodes > 60000) return ORBX_UNSUPPORTED;   // box labels are 16 bits
     const size_t lds = sizeof(int) * ((size_t)13 * dp.max_nodes + dp.cell_words);
     if (lds > 150 * 1024) return ORBX_UNSUPPORTED;
-    ORBX_HIP(hipFuncSetAttribute((const void*)k_distribute_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ORBX_TRY(ensure_dynamic_lds((const void*)k_distribute_level, lds));
     ORBX_TRY(h->d_labels.ensure((size_t)h->cand_cap * n_frames));
     ORBX_TRY(h->d_picked_idx.ensure((size_t)n_frames * kMaxLevels * dp.out_stride));
     ORBX_TRY(h->d_picked_n.ensure((size_t)n_frames * kMaxLevels));
@@ -1175,12 +1168,7 @@ orbx_status orbx_extract_batch(orbx_extractor* h, const uint8_t* d_images, int n
         };
         if (lds_form) {
             const size_t shmem = select_lds(kSelectMaxCands);
-            if (!h->select_attr_set || shmem > h->select_attr_bytes) {
-                ORBX_HIP(hipFuncSetAttribute((const void*)k_select_frame<false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                h->select_attr_set = true;
-                h->select_attr_bytes = shmem;
-            }
+            ORBX_TRY(ensure_dynamic_lds((const void*)k_select_frame<false>, shmem));
             const long half_cu = 80 * 1024 - 512;  // half of the CU's 160 KB, less the kernel's static LDS and rounding
             const long kp_area = (long)capacity * (long)(sizeof(orbx_keypoint) + sizeof(int));
             const int small_cands = (int)((half_cu - kp_area) / (long)sizeof(stdsel::Elem)) / 64 * 64;

@@ -1786,7 +1786,7 @@ struct orbx_matcher {
     DevBuf<int32_t> d_win_n, d_win_over;
     DevBuf<int2> d_win_list;
     DevBuf<uint8_t> d_recs, d_args;
-    size_t fast_lds_attr = 0, lists_lds_attr = 0, bow_lds_attr = 0, epi_lds_attr = 0;
+    size_t bow_lds_attr = 0, epi_lds_attr = 0;   // largest dynamic LDS the back-end matchers of this handle have asked for
     std::vector<unsigned long long> h_best;
     int hamming_kernel = 0;   // 0: matrix cores (k_bf_hamming_mfma), 1: vector pipes (k_bf_hamming)
 };
@@ -2161,10 +2161,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
         // the speculative resolve keeps five words per feature in LDS; beyond that use the sequential one
         hipLaunchKernelGGL(k_window_gather<0>, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A);
         const size_t lds = sizeof(int32_t) * 4 * (size_t)kp_capacity;
-        if (lds > 48 * 1024 && lds > h->lists_lds_attr) {
-            ORBX_HIP(hipFuncSetAttribute((const void*)k_resolve_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            h->lists_lds_attr = lds;
-        }
+        if (lds > 48 * 1024) ORBX_TRY(ensure_dynamic_lds((const void*)k_resolve_lists, lds));
         hipLaunchKernelGGL(k_resolve_lists, dim3(n_pairs), dim3(64), lds, s, A);
         ORBX_HIP(hipGetLastError());
         return ORBX_OK;
@@ -2176,10 +2173,7 @@ orbx_status orbx_match_projection_frame_batch(orbx_matcher* h, const orbx_grid* 
     hipLaunchKernelGGL(k_item_records, dim3(div_up(ncells, 256), n_pairs), dim3(256), 0, s, A, recs);
     hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(kp_capacity, 16), n_pairs), dim3(256), 0, s, A, recs);
     const size_t fast_lds = sizeof(int32_t) * 5 * (size_t)kp_capacity;
-    if (fast_lds > 48 * 1024 && fast_lds > h->fast_lds_attr) {
-        ORBX_HIP(hipFuncSetAttribute((const void*)k_resolve_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fast_lds));
-        h->fast_lds_attr = fast_lds;
-    }
+    if (fast_lds > 48 * 1024) ORBX_TRY(ensure_dynamic_lds((const void*)k_resolve_sorted, fast_lds));
     hipLaunchKernelGGL(k_resolve_sorted, dim3(n_pairs), dim3(64), fast_lds, s, A);
     ORBX_HIP(hipGetLastError());
     return ORBX_OK;
@@ -2323,10 +2317,8 @@ orbx_status upload_pack(orbx_matcher* h, const NodePack& P, size_t total_n, hipS
 }
 
 orbx_status raise_lds(const void* kernel, size_t bytes, size_t& current) {
-    if (bytes > 48 * 1024 && bytes > current) {
-        ORBX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        current = bytes;
-    }
+    if (bytes > 48 * 1024) ORBX_TRY(ensure_dynamic_lds(kernel, bytes));
+    current = std::max(current, bytes);
     return ORBX_OK;
 }
 
