@@ -383,6 +383,17 @@ def test_distribution_mode_bit_exact(oracle, test_images):
             assert np.array_equal(kps[f, :counts[f]], ok2.astype(orbx.KP_DTYPE)), (name, f)
             assert np.array_equal(desc[f, :counts[f]], od), (name, f)
             spread.append(len({(int(x) // 40, int(y) // 40) for x, y in zip(ok2["x"], ok2["y"])}))
+        # queued without host outputs and finished later: the same device results; the overflow of a later deferred
+        # batch is reported by finish()
+        ex.extract_batch(dev.data_ptr(), len(frames), w * h * ch, w, h, w * ch, ch, cap, to_host=False, deferred=True)
+        dcounts, redone = ex.finish()
+        assert not redone and np.array_equal(dcounts, counts), name
+        kp_ptr, desc_ptr, cnt_ptr, kcap = ex.device_results()
+        dkp = torch.as_tensor(_DevView(kp_ptr, (len(frames), kcap, 7), "<f4"), device="cuda").cpu().numpy().view(np.uint8)
+        dkp = np.ascontiguousarray(dkp).view(orbx.KP_DTYPE).reshape(len(frames), kcap)
+        ddesc = torch.as_tensor(_DevView(desc_ptr, (len(frames), kcap, 32), "|u1"), device="cuda").cpu().numpy()
+        for f in range(len(frames)):
+            assert np.array_equal(dkp[f, :counts[f]], kps[f, :counts[f]]) and np.array_equal(ddesc[f, :counts[f]], desc[f, :counts[f]])
         # one host frame through orbx_detect: a batch of one (so the border filter of the describe stage has run)
         k1 = ex.detect(frames[0])
         assert np.array_equal(k1, first.astype(orbx.KP_DTYPE)), name
@@ -409,6 +420,10 @@ def test_distribution_mode_bit_exact(oracle, test_images):
     ex.set_distribution(1, 7, 30)
     with pytest.raises(orbx.OrbxError) as e:
         ex.extract_batch(dev.data_ptr(), 2, 640 * 480, 640, 480, 640, 1, 800)
+    assert e.value.status == orbx.UNSUPPORTED
+    ex.extract_batch(dev.data_ptr(), 2, 640 * 480, 640, 480, 640, 1, 800, to_host=False, deferred=True)
+    with pytest.raises(orbx.OrbxError) as e:
+        ex.finish()
     assert e.value.status == orbx.UNSUPPORTED
     ex.close()
     # with the frame model of MonoFrame::extractFeatures (undistortion + bucket grid) on a larger batch
